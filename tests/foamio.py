@@ -1,0 +1,110 @@
+"""Test-side readers for the OpenFOAM LDU dumps under tests/golden/ and the
+seeded synthetic generators (numpy twins of the device generators).
+
+Format as read by the reference's parser (src/parser.c:29-107 there): scan for a
+keyword token, then `<count> ( v0 v1 ... )`.  Keyword order in the file is
+source, diag, upper, upperAddr, lowerAddr (tests/tests_cg.c:1095-1099 there);
+row = lowerAddr, col = upperAddr.
+"""
+import os
+import re
+
+import numpy as np
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _array(text, key, dtype):
+    m = re.search(r"(?<![A-Za-z])" + key + r"\s+(\d+)\s*\(", text)
+    if m is None:
+        raise ValueError("keyword %r not found" % key)
+    count = int(m.group(1))
+    end = text.index(")", m.end())
+    vals = np.array(text[m.end():end].split(), dtype=dtype)
+    if vals.size != count:
+        raise ValueError("%s: expected %d values, got %d" % (key, count, vals.size))
+    return vals
+
+
+def read_system(path):
+    """-> dict(n, U, source, diag, upper, rows(lowerAddr), cols(upperAddr))"""
+    with open(path) as f:
+        text = f.read()
+    source = _array(text, "source", np.float64)
+    diag = _array(text, "diag", np.float64)
+    upper = _array(text, "upper", np.float64)
+    cols = _array(text, "upperAddr", np.int32)
+    rows = _array(text, "lowerAddr", np.int32)
+    assert source.size == diag.size and upper.size == cols.size == rows.size
+    return dict(n=int(diag.size), U=int(upper.size), source=source, diag=diag,
+                upper=upper, rows=rows, cols=cols)
+
+
+def read_foam_field(path):
+    """internalField nonuniform List<scalar> reader (src/parser.c:109-177 there)."""
+    with open(path) as f:
+        lines = f.read().splitlines()
+    for k, line in enumerate(lines):
+        if "internalField   nonuniform List<scalar>" in line:
+            count = int(lines[k + 1].split()[0])
+            j = k + 2
+            while "(" not in lines[j]:
+                j += 1
+            return np.array([float(s) for s in lines[j + 1:j + 1 + count]], dtype=np.float64)
+    raise ValueError("internalField not found")
+
+
+def foam(name):
+    return read_system(os.path.join(GOLDEN, "cylinder_%s.system" % name))
+
+
+# --------------------------------------------------------------------------
+# Seeded synthetic matrices.  Pure functions of (seed, index): the device
+# generators in conjugate_gradient_amd/csrc/generate.hip use the same integer
+# hash, so host and device agree bit for bit (DESIGN.md "Generators").
+# --------------------------------------------------------------------------
+_M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def hash01(seed, idx):
+    """splitmix64 finaliser of (seed ^ idx*golden) -> double in [0,1)."""
+    with np.errstate(over="ignore"):
+        z = np.uint64(seed) ^ (np.asarray(idx, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15))
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    return (z >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
+
+
+def poisson_coo(nx, ny, nz, seed, points=7):
+    """Upper-triangular COO (row-sorted, columns ascending per row) of the 7- or
+    27-point stencil on an nx*ny*nz grid, row = x + nx*(y + ny*z).
+    off-diagonals -1.0; diag = (points-1) + 1e-3*hash01(seed,i);
+    b = hash01(seed+1,i) - 0.5."""
+    n = nx * ny * nz
+    idx = np.arange(n, dtype=np.int64)
+    x = idx % nx
+    y = (idx // nx) % ny
+    z = idx // (nx * ny)
+    if points == 7:
+        offs = [(0, 0, 1), (0, 1, 0), (1, 0, 0)]  # (dz,dy,dx): +1, +nx, +nx*ny
+    else:
+        offs = [(dz, dy, dx) for dz in (0, 1) for dy in (-1, 0, 1) for dx in (-1, 0, 1)
+                if (dz, dy, dx) > (0, 0, 0)]
+    rows, cols, order = [], [], []
+    for t, (dz, dy, dx) in enumerate(offs):
+        ok = ((x + dx >= 0) & (x + dx < nx) & (y + dy >= 0) & (y + dy < ny) & (z + dz < nz))
+        r = idx[ok]
+        rows.append(r)
+        cols.append(r + dx + nx * (dy + ny * dz))
+        order.append(np.full(r.size, t))
+    rows = np.concatenate(rows)
+    cols = np.concatenate(cols)
+    order = np.concatenate(order)
+    perm = np.lexsort((order, rows))
+    rows = rows[perm].astype(np.int32)
+    cols = cols[perm].astype(np.int32)
+    upper = np.full(rows.size, -1.0)
+    diag = float(points - 1) + 1e-3 * hash01(seed, idx)
+    b = hash01(seed + 1, idx) - 0.5
+    return dict(n=n, U=int(rows.size), diag=diag, upper=upper, rows=rows, cols=cols, source=b)
