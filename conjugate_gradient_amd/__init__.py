@@ -1,0 +1,8 @@
+"""conjugate_gradient_amd -- MI355X-native CG solver behind the reference's C API.
+
+The product is libcg_hip.so (hand-written HIP for gfx950, C ABI in include/*.h).
+This package is only the ctypes view of that ABI used by tests/ and bench.py;
+it carries no compute of its own and raises if the library or a GPU is missing.
+"""
+from .binding import (CgOpts, CgReport, DeviceVector, Matrix, lib, init, have_gpu,  # noqa: F401
+                      LAYOUT_ELL, LAYOUT_CSR, LAYOUT_SELL, LIB_PATH, cg_solve)

@@ -1,0 +1,203 @@
+"""ctypes binding of libcg_hip.so (include/cg_hip.h).  No fallback: a missing
+library or a failing call raises."""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libcg_hip.so")
+
+LAYOUT_ELL, LAYOUT_CSR, LAYOUT_SELL = 0, 1, 2
+
+dp = C.POINTER(C.c_double)
+ip = C.POINTER(C.c_int)
+
+
+class CgOpts(C.Structure):
+    _fields_ = [("max_iter", C.c_int), ("tol", C.c_double), ("strict", C.c_int),
+                ("check_every", C.c_int), ("fixed_iters", C.c_int), ("time_kernels", C.c_int)]
+
+
+class CgReport(C.Structure):
+    _fields_ = [("ret", C.c_int), ("iterations", C.c_int), ("initial_res", C.c_double),
+                ("final_res", C.c_double), ("r0", C.c_double * 5), ("solve_ms", C.c_double),
+                ("spmv_ms_avg", C.c_double)]
+
+
+_lib = None
+_inited = None
+
+
+def lib():
+    """Load libcg_hip.so (built by `make -C conjugate_gradient_amd/csrc`)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError("libcg_hip.so is not built: run `make -C conjugate_gradient_amd/csrc` "
+                           "(or __graft_entry__.build()); there is no CPU fallback")
+    L = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    vp = C.c_void_p
+    i64 = C.c_int64
+    L.cgh_init.argtypes = [C.c_int]
+    L.cgh_last_error.restype = C.c_char_p
+    L.cgh_alloc.argtypes = [C.c_size_t]
+    L.cgh_alloc.restype = vp
+    L.cgh_free.argtypes = [vp]
+    L.cgh_free.restype = None
+    for f in ("cgh_h2d", "cgh_d2h", "cgh_d2d"):
+        getattr(L, f).argtypes = [vp, vp, C.c_size_t]
+    L.cgh_memset.argtypes = [vp, C.c_int, C.c_size_t]
+    L.cgh_matrix_from_ell_host.argtypes = [i64, C.c_int, dp, dp, ip]
+    L.cgh_matrix_from_ell_host.restype = vp
+    L.cgh_matrix_from_coo_host.argtypes = [i64, i64, dp, dp, ip, ip, C.c_int]
+    L.cgh_matrix_from_coo_host.restype = vp
+    L.cgh_matrix_from_coo_device.argtypes = [i64, i64, vp, vp, vp, vp, C.c_int]
+    L.cgh_matrix_from_coo_device.restype = vp
+    L.cgh_matrix_poisson.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_int, vp]
+    L.cgh_matrix_poisson.restype = vp
+    L.cgh_matrix_free.argtypes = [vp]
+    L.cgh_matrix_free.restype = None
+    for f in ("cgh_matrix_rows", "cgh_matrix_nnz_offdiag", "cgh_matrix_stored_bytes"):
+        getattr(L, f).argtypes = [vp]
+        getattr(L, f).restype = i64
+    for f in ("cgh_matrix_width", "cgh_matrix_layout"):
+        getattr(L, f).argtypes = [vp]
+    L.cgh_matrix_download_ell.argtypes = [vp, dp, ip]
+    L.cgh_matrix_download_diag.argtypes = [vp, dp]
+    L.cgh_spmv.argtypes = [vp, vp, vp]
+    L.cgh_dot.argtypes = [vp, vp, i64, C.c_int, dp]
+    L.cgh_l1norm.argtypes = [vp, i64, C.c_int, dp]
+    L.cgh_axpy.argtypes = [vp, vp, C.c_double, vp, i64]
+    L.cgh_cg_solve.argtypes = [vp, vp, vp, C.POINTER(CgOpts), C.POINTER(CgReport), dp]
+    L.cgh_time_spmv.argtypes = [vp, vp, vp, C.c_int, dp]
+    L.cgh_time_copy.argtypes = [vp, vp, C.c_size_t, C.c_int, dp]
+    _lib = L
+    return L
+
+
+def check(rc, what="libcg_hip call"):
+    if rc != 0:
+        raise RuntimeError("%s failed (%d): %s" % (what, rc, lib().cgh_last_error().decode()))
+
+
+def have_gpu():
+    return lib().cgh_device_count() > 0
+
+
+def init(device=0):
+    global _inited
+    if _inited != device:
+        check(lib().cgh_init(device), "cgh_init")
+        _inited = device
+
+
+def _D(a):
+    assert a.dtype == np.float64 and a.flags.c_contiguous
+    return a.ctypes.data_as(dp)
+
+
+def _I(a):
+    assert a.dtype == np.int32 and a.flags.c_contiguous
+    return a.ctypes.data_as(ip)
+
+
+class DeviceVector:
+    """A device buffer of `count` elements of `dtype` (hipMalloc via the library)."""
+
+    def __init__(self, count, dtype=np.float64):
+        self.count = int(count)
+        self.dtype = np.dtype(dtype)
+        self.nbytes = self.count * self.dtype.itemsize
+        self.ptr = lib().cgh_alloc(max(self.nbytes, 16))
+        if not self.ptr:
+            raise MemoryError(lib().cgh_last_error().decode())
+
+    @classmethod
+    def from_host(cls, a):
+        a = np.ascontiguousarray(a)
+        v = cls(a.size, a.dtype)
+        check(lib().cgh_h2d(v.ptr, a.ctypes.data, v.nbytes), "h2d")
+        return v
+
+    def to_host(self):
+        out = np.empty(self.count, dtype=self.dtype)
+        check(lib().cgh_d2h(out.ctypes.data, self.ptr, self.nbytes), "d2h")
+        return out
+
+    def zero(self):
+        check(lib().cgh_memset(self.ptr, 0, self.nbytes), "memset")
+
+    def free(self):
+        if self.ptr:
+            lib().cgh_free(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Matrix:
+    def __init__(self, handle):
+        if not handle:
+            raise RuntimeError("matrix construction failed: " + lib().cgh_last_error().decode())
+        self.h = handle
+
+    @classmethod
+    def from_ell(cls, n, K, diag, ev, ec):
+        return cls(lib().cgh_matrix_from_ell_host(n, K, _D(diag), _D(ev), _I(ec)))
+
+    @classmethod
+    def from_coo(cls, n, diag, upper, rows, cols, layout=LAYOUT_ELL):
+        return cls(lib().cgh_matrix_from_coo_host(n, rows.size, _D(diag), _D(upper), _I(rows), _I(cols), layout))
+
+    @classmethod
+    def poisson(cls, nx, ny, nz, points, seed, layout=LAYOUT_ELL, b=None):
+        return cls(lib().cgh_matrix_poisson(nx, ny, nz, points, seed, layout, b.ptr if b is not None else None))
+
+    n = property(lambda self: lib().cgh_matrix_rows(self.h))
+    K = property(lambda self: lib().cgh_matrix_width(self.h))
+    nnz_offdiag = property(lambda self: lib().cgh_matrix_nnz_offdiag(self.h))
+    layout = property(lambda self: lib().cgh_matrix_layout(self.h))
+    stored_bytes = property(lambda self: lib().cgh_matrix_stored_bytes(self.h))
+
+    def download_ell(self):
+        ev = np.empty(self.n * self.K)
+        ec = np.empty(self.n * self.K, dtype=np.int32)
+        check(lib().cgh_matrix_download_ell(self.h, _D(ev), _I(ec)), "download_ell")
+        return ev, ec
+
+    def download_diag(self):
+        d = np.empty(self.n)
+        check(lib().cgh_matrix_download_diag(self.h, _D(d)), "download_diag")
+        return d
+
+    def spmv(self, x, y):
+        check(lib().cgh_spmv(self.h, x.ptr, y.ptr), "cgh_spmv")
+
+    def free(self):
+        if self.h:
+            lib().cgh_matrix_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def cg_solve(mat, b, x, max_iter=1000, tol=1e-6, strict=0, check_every=0, fixed_iters=0, time_kernels=0,
+             history=True):
+    """-> (CgReport, history[iterations+1, 4] or None)"""
+    opts = CgOpts(max_iter, tol, strict, check_every, fixed_iters, time_kernels)
+    rep = CgReport()
+    cap = (fixed_iters + 2) if fixed_iters > 0 else max_iter + 1
+    hist = np.full((cap, 4), np.nan) if history else None
+    check(lib().cgh_cg_solve(mat.h, b.ptr, x.ptr, C.byref(opts), C.byref(rep),
+                             _D(hist) if history else None), "cgh_cg_solve")
+    return rep, (hist[:rep.iterations + 1] if history else None)

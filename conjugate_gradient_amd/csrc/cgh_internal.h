@@ -1,0 +1,94 @@
+// cgh_internal.h -- shared internals of libcg_hip (not installed).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include "../../include/cg_hip.h"
+
+struct cgh_context {
+    bool        ready = false;
+    int         device = -1;
+    int         num_cu = 256;
+    hipStream_t stream = nullptr;       // compute stream: every kernel of the solver
+    hipStream_t comm_stream = nullptr;  // halo exchange / collectives (multi-GPU)
+    char        err[512] = {0};
+};
+extern cgh_context g_cgh;
+
+void cgh_set_error(const char *fmt, ...);
+
+#define CGH_HIP(call)                                                                       \
+    do {                                                                                    \
+        hipError_t e_ = (call);                                                             \
+        if (e_ != hipSuccess) {                                                             \
+            cgh_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); \
+            return CGH_EHIP;                                                                \
+        }                                                                                   \
+    } while (0)
+
+#define CGH_HIP_NULL(call)                                                                  \
+    do {                                                                                    \
+        hipError_t e_ = (call);                                                             \
+        if (e_ != hipSuccess) {                                                             \
+            cgh_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); \
+            return nullptr;                                                                 \
+        }                                                                                   \
+    } while (0)
+
+#define CGH_REQUIRE_READY(ret)                                                              \
+    do {                                                                                    \
+        if (!g_cgh.ready) {                                                                 \
+            cgh_set_error("libcg_hip: cgh_init() has not been called (or no GPU)");          \
+            return ret;                                                                     \
+        }                                                                                   \
+    } while (0)
+
+// ---------------------------------------------------------------- matrices
+struct cgh_matrix {
+    int64_t n = 0;
+    int     K = 0;               // max off-diagonals per row
+    int     layout = CGH_LAYOUT_ELL;
+    int64_t nnz_off = 0;         // stored non-pad off-diagonals
+    double *diag = nullptr;      // [n]
+    // ELL (slot-major): vals/cols [K*n]
+    // CSR: vals/cols [nnz_off], row_ptr [n+1]
+    // SELL: vals/cols [slice_ptr[nslices]], slice_ptr [nslices+1] (entry offsets), slice width = (ptr[s+1]-ptr[s])/64
+    double  *vals = nullptr;
+    int     *cols = nullptr;
+    int64_t *row_ptr = nullptr;
+    int64_t *slice_ptr = nullptr;
+    int64_t  nslices = 0;
+    int64_t  stored = 0;         // stored entries incl. padding
+    // CSR-adaptive row bins (row ids sorted into length classes), built once at construction
+    int     *bin_rows = nullptr; // [n] row ids grouped by bin
+    int64_t  bin_start[5] = {0, 0, 0, 0, 0}; // short / sub-wave / wave / block rows
+    bool     owns = true;
+};
+
+// ------------------------------------------------------------ launch shapes
+constexpr int CGH_BLOCK = 256;          // 4 waves of 64
+constexpr int CGH_MAX_PARTIALS = 2048;  // upper bound on any reducing grid
+
+// Number of blocks for a grid-stride streaming / reducing kernel over `tiles` tiles.
+static inline int cgh_stream_grid(int64_t tiles, int blocks_per_cu)
+{
+    int64_t g = (int64_t)g_cgh.num_cu * blocks_per_cu;
+    if (g > CGH_MAX_PARTIALS) g = CGH_MAX_PARTIALS;
+    if (g > tiles) g = tiles;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+// --------------------------------------------------------------- kernels (host launchers)
+// spmv.hip
+int cgh_launch_spmv(const cgh_matrix *m, const double *x, double *y, double *dot_partials, int *grid_out,
+                    const int *done_flag, hipStream_t s);
+int cgh_spmv_grid(const cgh_matrix *m);
+
+// blas1.hip
+struct cgh_cg_ws;  // solver workspace

@@ -1,0 +1,51 @@
+// device_utils.h -- wave64 / workgroup reduction helpers and exact-rounding arithmetic.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+// Rounded multiply then rounded add, never contracted into an FMA: the
+// reference is built without FMA contraction (its Makefile: -std=c99), and its
+// results are reproduced bit for bit only if each product is rounded first.
+// The translation units are also compiled with -ffp-contract=off.
+__device__ __forceinline__ double mul_rn(double a, double b) { return __dmul_rn(a, b); }
+__device__ __forceinline__ double add_rn(double a, double b) { return __dadd_rn(a, b); }
+__device__ __forceinline__ double madd_rn(double acc, double a, double b) { return __dadd_rn(acc, __dmul_rn(a, b)); }
+
+// Sum over the 64 lanes of a wave (result valid in lane 0; fixed order).
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+// Sum over a 256-thread workgroup; result valid in thread 0.  `lds` holds >= 4 doubles.
+// The order (lane tree, then waves 0..3 left to right) is fixed, so the result is
+// run-to-run deterministic for a fixed launch shape.
+__device__ __forceinline__ double block_sum_256(double v, double *lds)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    v = wave_sum(v);
+    if (lane == 0) lds[wave] = v;
+    __syncthreads();
+    double total = 0.0;
+    if (threadIdx.x == 0) total = ((lds[0] + lds[1]) + lds[2]) + lds[3];
+    __syncthreads();
+    return total;
+}
+
+// Every thread of a 256-thread workgroup gets the sum of parts[0..count) (count <= 2048),
+// accumulated in a fixed order that is the same in every workgroup, so all workgroups of
+// a launch derive bit-identical scalars from the same partials.
+__device__ __forceinline__ double block_sum_partials(const double *parts, int count, int stride, double *lds)
+{
+    double v = 0.0;
+    for (int k = threadIdx.x; k < count; k += 256) v += parts[(size_t)k * stride];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    v = wave_sum(v);
+    if (lane == 0) lds[wave] = v;
+    __syncthreads();
+    double total = ((lds[0] + lds[1]) + lds[2]) + lds[3];
+    __syncthreads();
+    return total;
+}

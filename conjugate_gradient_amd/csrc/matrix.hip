@@ -1,0 +1,171 @@
+// matrix.hip -- cgh_matrix lifetime, SpMV dispatch and the benchmark timing helpers.
+#include <vector>
+
+#include "cgh_internal.h"
+
+int cgh_launch_spmv_ell(const cgh_matrix *m, const double *x, double *y, double *dot_partials, int *grid_out,
+                        const int *done, hipStream_t s);
+int cgh_launch_spmv_csr(const cgh_matrix *m, const double *x, double *y, double *dot_partials, int *grid_out,
+                        const int *done, hipStream_t s);
+int cgh_launch_spmv_sell(const cgh_matrix *m, const double *x, double *y, double *dot_partials, int *grid_out,
+                         const int *done, hipStream_t s);
+int cgh_csr_to_ell_download(const cgh_matrix *m, double *ell_vals, int *ell_cols);
+
+int cgh_launch_spmv(const cgh_matrix *m, const double *x, double *y, double *dot_partials, int *grid_out,
+                    const int *done, hipStream_t s)
+{
+    switch (m->layout) {
+    case CGH_LAYOUT_ELL: return cgh_launch_spmv_ell(m, x, y, dot_partials, grid_out, done, s);
+    case CGH_LAYOUT_CSR: return cgh_launch_spmv_csr(m, x, y, dot_partials, grid_out, done, s);
+    case CGH_LAYOUT_SELL: return cgh_launch_spmv_sell(m, x, y, dot_partials, grid_out, done, s);
+    }
+    cgh_set_error("cgh_spmv: unknown layout %d", m->layout);
+    return CGH_EINVAL;
+}
+
+namespace {
+
+__global__ __launch_bounds__(256) void copy16(const uint4 *__restrict__ src, uint4 *__restrict__ dst, size_t count)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+}
+
+} // namespace
+
+extern "C" {
+
+cgh_matrix *cgh_matrix_from_ell_host(int64_t n, int K, const double *diag, const double *ell_vals, const int *ell_cols)
+{
+    CGH_REQUIRE_READY(nullptr);
+    if (n <= 0 || K < 0 || !diag || (K > 0 && (!ell_vals || !ell_cols))) {
+        cgh_set_error("cgh_matrix_from_ell_host: bad arguments (n=%lld K=%d)", (long long)n, K);
+        return nullptr;
+    }
+    cgh_matrix *m = new cgh_matrix();
+    m->n = n;
+    m->K = K;
+    m->layout = CGH_LAYOUT_ELL;
+    m->stored = n * (int64_t)K;
+    m->diag = (double *)cgh_alloc(sizeof(double) * (size_t)n);
+    m->vals = (double *)cgh_alloc(sizeof(double) * (size_t)m->stored);
+    m->cols = (int *)cgh_alloc(sizeof(int) * (size_t)m->stored);
+    if (!m->diag || !m->vals || !m->cols) {
+        cgh_matrix_free(m);
+        return nullptr;
+    }
+    if (cgh_h2d(m->diag, diag, sizeof(double) * (size_t)n) || cgh_h2d(m->vals, ell_vals, sizeof(double) * (size_t)m->stored) ||
+        cgh_h2d(m->cols, ell_cols, sizeof(int) * (size_t)m->stored)) {
+        cgh_matrix_free(m);
+        return nullptr;
+    }
+    int64_t nz = 0;
+    for (int64_t k = 0; k < m->stored; ++k) nz += ell_cols[k] != -1;
+    m->nnz_off = nz;
+    return m;
+}
+
+void cgh_matrix_free(cgh_matrix *m)
+{
+    if (!m) return;
+    if (m->owns) {
+        cgh_free(m->diag);
+        cgh_free(m->vals);
+        cgh_free(m->cols);
+        cgh_free(m->row_ptr);
+        cgh_free(m->slice_ptr);
+        cgh_free(m->bin_rows);
+    }
+    delete m;
+}
+
+int64_t cgh_matrix_rows(const cgh_matrix *m) { return m ? m->n : 0; }
+int     cgh_matrix_width(const cgh_matrix *m) { return m ? m->K : 0; }
+int64_t cgh_matrix_nnz_offdiag(const cgh_matrix *m) { return m ? m->nnz_off : 0; }
+int     cgh_matrix_layout(const cgh_matrix *m) { return m ? m->layout : -1; }
+
+int64_t cgh_matrix_stored_bytes(const cgh_matrix *m)
+{
+    if (!m) return 0;
+    int64_t b = m->stored * 12 + m->n * 8;
+    if (m->layout == CGH_LAYOUT_CSR) b += (m->n + 1) * 8;
+    if (m->layout == CGH_LAYOUT_SELL) b += (m->nslices + 1) * 8;
+    return b;
+}
+
+int cgh_matrix_download_diag(const cgh_matrix *m, double *diag)
+{
+    CGH_REQUIRE_READY(CGH_ENODEV);
+    return cgh_d2h(diag, m->diag, sizeof(double) * (size_t)m->n);
+}
+
+int cgh_matrix_download_ell(const cgh_matrix *m, double *ell_vals, int *ell_cols)
+{
+    CGH_REQUIRE_READY(CGH_ENODEV);
+    if (!m) return CGH_EINVAL;
+    if (m->layout == CGH_LAYOUT_ELL) {
+        int rc = cgh_d2h(ell_vals, m->vals, sizeof(double) * (size_t)m->stored);
+        if (rc) return rc;
+        return cgh_d2h(ell_cols, m->cols, sizeof(int) * (size_t)m->stored);
+    }
+    return cgh_csr_to_ell_download(m, ell_vals, ell_cols);
+}
+
+int cgh_spmv(const cgh_matrix *m, const double *d_x, double *d_y)
+{
+    CGH_REQUIRE_READY(CGH_ENODEV);
+    if (!m || !d_x || !d_y) {
+        cgh_set_error("cgh_spmv: NULL argument");
+        return CGH_EINVAL;
+    }
+    return cgh_launch_spmv(m, d_x, d_y, nullptr, nullptr, nullptr, g_cgh.stream);
+}
+
+int cgh_time_spmv(const cgh_matrix *m, const double *d_x, double *d_y, int reps, double *ms_avg)
+{
+    CGH_REQUIRE_READY(CGH_ENODEV);
+    if (!m || reps < 1) return CGH_EINVAL;
+    hipStream_t s = g_cgh.stream;
+    hipEvent_t  a, b;
+    CGH_HIP(hipEventCreate(&a));
+    CGH_HIP(hipEventCreate(&b));
+    int rc = cgh_launch_spmv(m, d_x, d_y, nullptr, nullptr, nullptr, s);  // warm-up
+    if (rc) return rc;
+    CGH_HIP(hipEventRecord(a, s));
+    for (int k = 0; k < reps; ++k) {
+        rc = cgh_launch_spmv(m, d_x, d_y, nullptr, nullptr, nullptr, s);
+        if (rc) return rc;
+    }
+    CGH_HIP(hipEventRecord(b, s));
+    CGH_HIP(hipStreamSynchronize(s));
+    float ms = 0.f;
+    CGH_HIP(hipEventElapsedTime(&ms, a, b));
+    (void)hipEventDestroy(a);
+    (void)hipEventDestroy(b);
+    *ms_avg = (double)ms / reps;
+    return CGH_OK;
+}
+
+int cgh_time_copy(void *d_dst, const void *d_src, size_t bytes, int reps, double *ms_avg)
+{
+    CGH_REQUIRE_READY(CGH_ENODEV);
+    if (bytes % 16 || reps < 1) return CGH_EINVAL;
+    hipStream_t s = g_cgh.stream;
+    hipEvent_t  a, b;
+    CGH_HIP(hipEventCreate(&a));
+    CGH_HIP(hipEventCreate(&b));
+    const int grid = g_cgh.num_cu * 8;
+    hipLaunchKernelGGL(copy16, dim3(grid), dim3(256), 0, s, (const uint4 *)d_src, (uint4 *)d_dst, bytes / 16);
+    CGH_HIP(hipEventRecord(a, s));
+    for (int k = 0; k < reps; ++k)
+        hipLaunchKernelGGL(copy16, dim3(grid), dim3(256), 0, s, (const uint4 *)d_src, (uint4 *)d_dst, bytes / 16);
+    CGH_HIP(hipEventRecord(b, s));
+    CGH_HIP(hipStreamSynchronize(s));
+    float ms = 0.f;
+    CGH_HIP(hipEventElapsedTime(&ms, a, b));
+    (void)hipEventDestroy(a);
+    (void)hipEventDestroy(b);
+    *ms_avg = (double)ms / reps;
+    return CGH_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,128 @@
+// runtime.hip -- device selection, streams, raw buffers (C ABI: include/cg_hip.h "runtime").
+#include <cstdarg>
+
+#include "cgh_internal.h"
+
+cgh_context g_cgh;
+
+void cgh_set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_cgh.err, sizeof g_cgh.err, fmt, ap);
+    va_end(ap);
+    if (!getenv("CG_HIP_SILENT_ERRORS")) fprintf(stderr, "libcg_hip: %s\n", g_cgh.err);
+}
+
+extern "C" {
+
+const char *cgh_last_error(void) { return g_cgh.err; }
+
+int cgh_device_count(void)
+{
+    int c = 0;
+    if (hipGetDeviceCount(&c) != hipSuccess) return 0;
+    return c;
+}
+
+int cgh_init(int device)
+{
+    if (g_cgh.ready && g_cgh.device == device) return CGH_OK;
+    if (g_cgh.ready) cgh_shutdown();
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count == 0) {
+        cgh_set_error("cgh_init: no HIP device visible (%s)", e == hipSuccess ? "count=0" : hipGetErrorString(e));
+        return CGH_ENODEV;
+    }
+    if (device < 0 || device >= count) {
+        cgh_set_error("cgh_init: device %d out of range [0,%d)", device, count);
+        return CGH_EINVAL;
+    }
+    CGH_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    CGH_HIP(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        cgh_set_error("cgh_init: device %d is %s; this library carries gfx950 (MI355X) code only", device, prop.gcnArchName);
+        return CGH_ENODEV;
+    }
+    g_cgh.num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    CGH_HIP(hipStreamCreateWithFlags(&g_cgh.stream, hipStreamNonBlocking));
+    CGH_HIP(hipStreamCreateWithFlags(&g_cgh.comm_stream, hipStreamNonBlocking));
+    g_cgh.device = device;
+    g_cgh.ready = true;
+    return CGH_OK;
+}
+
+void cgh_shutdown(void)
+{
+    if (!g_cgh.ready) return;
+    (void)hipDeviceSynchronize();
+    if (g_cgh.stream) (void)hipStreamDestroy(g_cgh.stream);
+    if (g_cgh.comm_stream) (void)hipStreamDestroy(g_cgh.comm_stream);
+    g_cgh.stream = g_cgh.comm_stream = nullptr;
+    g_cgh.ready = false;
+    g_cgh.device = -1;
+}
+
+int cgh_sync(void)
+{
+    CGH_REQUIRE_READY(CGH_ENODEV);
+    CGH_HIP(hipStreamSynchronize(g_cgh.stream));
+    CGH_HIP(hipStreamSynchronize(g_cgh.comm_stream));
+    return CGH_OK;
+}
+
+void *cgh_alloc(size_t bytes)
+{
+    CGH_REQUIRE_READY(nullptr);
+    void *p = nullptr;
+    if (bytes == 0) bytes = 16;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) {
+        cgh_set_error("cgh_alloc(%zu): %s", bytes, hipGetErrorString(e));
+        return nullptr;
+    }
+    return p;
+}
+
+void cgh_free(void *d_ptr)
+{
+    if (d_ptr && g_cgh.ready) (void)hipFree(d_ptr);
+}
+
+int cgh_h2d(void *d_dst, const void *h_src, size_t bytes)
+{
+    CGH_REQUIRE_READY(CGH_ENODEV);
+    if (bytes == 0) return CGH_OK;
+    CGH_HIP(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, g_cgh.stream));
+    CGH_HIP(hipStreamSynchronize(g_cgh.stream));
+    return CGH_OK;
+}
+
+int cgh_d2h(void *h_dst, const void *d_src, size_t bytes)
+{
+    CGH_REQUIRE_READY(CGH_ENODEV);
+    if (bytes == 0) return CGH_OK;
+    CGH_HIP(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, g_cgh.stream));
+    CGH_HIP(hipStreamSynchronize(g_cgh.stream));
+    return CGH_OK;
+}
+
+int cgh_d2d(void *d_dst, const void *d_src, size_t bytes)
+{
+    CGH_REQUIRE_READY(CGH_ENODEV);
+    if (bytes == 0) return CGH_OK;
+    CGH_HIP(hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, g_cgh.stream));
+    return CGH_OK;
+}
+
+int cgh_memset(void *d_dst, int byte, size_t bytes)
+{
+    CGH_REQUIRE_READY(CGH_ENODEV);
+    if (bytes == 0) return CGH_OK;
+    CGH_HIP(hipMemsetAsync(d_dst, byte, bytes, g_cgh.stream));
+    return CGH_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,196 @@
+// spmv_ell.hip -- y = A x for the slot-major ("column-major") full ELL layout.
+//
+// Replaces reference src/ell.c:1004-1040 (mv_ell_symmetric_full_colmajor): entry (row i, slot s)
+// lives at s*n+i, pad = col -1.  One thread owns R consecutive rows and keeps y[i] in a register,
+// adding diag first and then slots 0..K-1 with pads skipped -- the same sequence of rounded
+// multiplies and adds the reference performs on y[i], so the result is bit-identical.
+//
+// HBM-bound: per row it streams K*(8+4) matrix bytes + diag 8 + y 8 and gathers x.  Slot streams
+// are read with 16-B (values) / 8-B (columns) per-lane loads, fully coalesced because consecutive
+// lanes own consecutive row pairs of one slot.  Workgroups walk the 512-row tiles grid-stride with
+// a grid that is a multiple of 8, so tile t always runs on the XCD group t%8 and the co-resident
+// workgroups form one moving front; the gathered x lines (stencil neighbours) are then re-used
+// from that XCD's L2 while the matrix streams through once.
+//
+// DOT=true additionally leaves sum_i x[i]*y[i] of the workgroup's rows in partials[blockIdx.x]
+// (CG: x is p, y is Ap; saves a full re-read of p and Ap).
+#include "cgh_internal.h"
+#include "device_utils.h"
+
+namespace {
+
+typedef double d2_t __attribute__((ext_vector_type(2)));
+typedef int    i2_t __attribute__((ext_vector_type(2)));
+
+// Matrix values/columns are read exactly once per SpMV: non-temporal loads keep them from
+// displacing the gathered x lines in L2.
+template <typename T>
+__device__ __forceinline__ T stream_load(const T *p)
+{
+#ifdef CGH_NO_NT
+    return *p;
+#else
+    return __builtin_nontemporal_load(p);
+#endif
+}
+
+template <int KT, bool DOT>
+__global__ __launch_bounds__(CGH_BLOCK) void spmv_ell_r2(int64_t n, int Krt, const double *__restrict__ diag,
+                                                        const double *__restrict__ vals, const int *__restrict__ cols,
+                                                        const double *__restrict__ x, double *__restrict__ y,
+                                                        double *__restrict__ partials, const int *__restrict__ done)
+{
+    __shared__ double lds[4];
+    if (done != nullptr && *done != 0) return;
+    const int     K = KT > 0 ? KT : Krt;
+    const int64_t pairs = n >> 1;  // n is even on this path
+    double        local = 0.0;
+
+    for (int64_t pr = (int64_t)blockIdx.x * CGH_BLOCK + threadIdx.x; pr < pairs; pr += (int64_t)gridDim.x * CGH_BLOCK) {
+        const int64_t i0 = pr << 1;
+        const double2 d = *reinterpret_cast<const double2 *>(diag + i0);
+        const double2 xi = *reinterpret_cast<const double2 *>(x + i0);
+        double        a0 = add_rn(0.0, mul_rn(d.x, xi.x));
+        double        a1 = add_rn(0.0, mul_rn(d.y, xi.y));
+        if constexpr (KT > 0) {
+            d2_t v[KT];
+            i2_t c[KT];
+#pragma unroll
+            for (int s = 0; s < KT; ++s) {
+                c[s] = stream_load(reinterpret_cast<const i2_t *>(cols + (int64_t)s * n + i0));
+                v[s] = stream_load(reinterpret_cast<const d2_t *>(vals + (int64_t)s * n + i0));
+            }
+            double g0[KT], g1[KT];
+#pragma unroll
+            for (int s = 0; s < KT; ++s) {
+                g0[s] = x[c[s].x >= 0 ? (int64_t)c[s].x : i0];
+                g1[s] = x[c[s].y >= 0 ? (int64_t)c[s].y : i0];
+            }
+#pragma unroll
+            for (int s = 0; s < KT; ++s) {
+                const double t0 = madd_rn(a0, v[s].x, g0[s]);
+                const double t1 = madd_rn(a1, v[s].y, g1[s]);
+                a0 = c[s].x >= 0 ? t0 : a0;
+                a1 = c[s].y >= 0 ? t1 : a1;
+            }
+        } else {
+#pragma unroll 4
+            for (int s = 0; s < K; ++s) {
+                const i2_t    c = stream_load(reinterpret_cast<const i2_t *>(cols + (int64_t)s * n + i0));
+                const d2_t    v = stream_load(reinterpret_cast<const d2_t *>(vals + (int64_t)s * n + i0));
+                const double  g0 = x[c.x >= 0 ? (int64_t)c.x : i0];
+                const double  g1 = x[c.y >= 0 ? (int64_t)c.y : i0];
+                const double  t0 = madd_rn(a0, v.x, g0);
+                const double  t1 = madd_rn(a1, v.y, g1);
+                a0 = c.x >= 0 ? t0 : a0;
+                a1 = c.y >= 0 ? t1 : a1;
+            }
+        }
+        *reinterpret_cast<double2 *>(y + i0) = make_double2(a0, a1);
+        if constexpr (DOT) local += xi.x * a0 + xi.y * a1;
+    }
+    if constexpr (DOT) {
+        const double tot = block_sum_256(local, lds);
+        if (threadIdx.x == 0) partials[blockIdx.x] = tot;
+    }
+}
+
+// Any n, any alignment: one row per thread.
+template <bool DOT>
+__global__ __launch_bounds__(CGH_BLOCK) void spmv_ell_r1(int64_t n, int K, const double *__restrict__ diag,
+                                                        const double *__restrict__ vals, const int *__restrict__ cols,
+                                                        const double *__restrict__ x, double *__restrict__ y,
+                                                        double *__restrict__ partials, const int *__restrict__ done)
+{
+    __shared__ double lds[4];
+    if (done != nullptr && *done != 0) return;
+    double local = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * CGH_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * CGH_BLOCK) {
+        const double xi = x[i];
+        double       a = add_rn(0.0, mul_rn(diag[i], xi));
+#pragma unroll 4
+        for (int s = 0; s < K; ++s) {
+            const int    c = cols[(int64_t)s * n + i];
+            const double v = vals[(int64_t)s * n + i];
+            const double g = x[c >= 0 ? (int64_t)c : i];
+            const double t = madd_rn(a, v, g);
+            a = c >= 0 ? t : a;
+        }
+        y[i] = a;
+        if constexpr (DOT) local += xi * a;
+    }
+    if constexpr (DOT) {
+        const double tot = block_sum_256(local, lds);
+        if (threadIdx.x == 0) partials[blockIdx.x] = tot;
+    }
+}
+
+inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+template <bool DOT>
+void launch_r2(int K, int grid, hipStream_t s, int64_t n, const double *diag, const double *vals, const int *cols,
+               const double *x, double *y, double *partials, const int *done)
+{
+#define CGH_ELL_CASE(KK)                                                                                       \
+    case KK:                                                                                                   \
+        hipLaunchKernelGGL((spmv_ell_r2<KK, DOT>), dim3(grid), dim3(CGH_BLOCK), 0, s, n, K, diag, vals, cols, x, y, \
+                           partials, done);                                                                    \
+        break;
+    switch (K) {
+        CGH_ELL_CASE(1)
+        CGH_ELL_CASE(2)
+        CGH_ELL_CASE(3)
+        CGH_ELL_CASE(4)
+        CGH_ELL_CASE(5)
+        CGH_ELL_CASE(6)
+        CGH_ELL_CASE(7)
+        CGH_ELL_CASE(8)
+        CGH_ELL_CASE(13)
+        CGH_ELL_CASE(26)
+    default:
+        hipLaunchKernelGGL((spmv_ell_r2<0, DOT>), dim3(grid), dim3(CGH_BLOCK), 0, s, n, K, diag, vals, cols, x, y,
+                           partials, done);
+    }
+#undef CGH_ELL_CASE
+}
+
+} // namespace
+
+// Rows per thread on the vector path.
+static inline bool ell_vector_path(const cgh_matrix *m, const double *x, const double *y)
+{
+    return (m->n % 2 == 0) && aligned16(x) && aligned16(y) && aligned16(m->vals) && aligned16(m->diag) &&
+           (reinterpret_cast<uintptr_t>(m->cols) & 7u) == 0;
+}
+
+int cgh_ell_grid(const cgh_matrix *m)
+{
+    // tiles of 512 rows (256 threads x 2 rows); grid a multiple of 8 so tile%8 -> XCD group is stable
+    const int64_t tiles = (m->n + 2 * CGH_BLOCK - 1) / (2 * CGH_BLOCK);
+    int           g = cgh_stream_grid(tiles, 8);
+    if (g >= 8) g -= g % 8;
+    return g;
+}
+
+int cgh_launch_spmv_ell(const cgh_matrix *m, const double *x, double *y, double *dot_partials, int *grid_out,
+                        const int *done, hipStream_t s)
+{
+    const int grid = cgh_ell_grid(m);
+    if (grid_out) *grid_out = grid;
+    if (m->n == 0) return CGH_OK;
+    if (ell_vector_path(m, x, y)) {
+        if (dot_partials)
+            launch_r2<true>(m->K, grid, s, m->n, m->diag, m->vals, m->cols, x, y, dot_partials, done);
+        else
+            launch_r2<false>(m->K, grid, s, m->n, m->diag, m->vals, m->cols, x, y, nullptr, done);
+    } else {
+        if (dot_partials)
+            hipLaunchKernelGGL((spmv_ell_r1<true>), dim3(grid), dim3(CGH_BLOCK), 0, s, m->n, m->K, m->diag, m->vals,
+                               m->cols, x, y, dot_partials, done);
+        else
+            hipLaunchKernelGGL((spmv_ell_r1<false>), dim3(grid), dim3(CGH_BLOCK), 0, s, m->n, m->K, m->diag, m->vals,
+                               m->cols, x, y, nullptr, done);
+    }
+    CGH_HIP(hipGetLastError());
+    return CGH_OK;
+}

@@ -1,0 +1,139 @@
+/*
+ * cg_hip.h -- device-resident C ABI of libcg_hip (MI355X / gfx950).
+ *
+ * The reference (Gabrocecco/conjugate_gradient) has no handles: its API is the
+ * plain functions of include/cg.h, csr.h, ell.h, vec.h, coo.h, all taking host
+ * pointers (reference include/cg.h:4-56, ell.h:75-158, csr.h:26-53,
+ * vec.h:26-46, coo.h:23-30).  This repo's include/{cg,csr,ell,vec,coo}.h keep
+ * those signatures; each such entry point is a thin wrapper
+ *     upload -> cgh_* below -> download
+ * so the functions here are what a caller uses to keep the matrix and the
+ * vectors resident in HBM across calls (benchmarks, long solves, multi-GPU).
+ *
+ * Conventions: plain C, no structs cross the boundary except the two POD
+ * option/report structs below; sizes are 64-bit; every function returning int
+ * returns 0 on success and a negative CGH_E* code on failure, with a message
+ * available from cgh_last_error().  Pointers named d_* are device pointers
+ * obtained from cgh_alloc().  The library is not thread-safe; one host thread
+ * drives one device (one process per GPU for multi-GPU).
+ */
+#ifndef CG_HIP_H
+#define CG_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+    CGH_OK = 0,
+    CGH_EHIP = -1,       /* a HIP runtime call failed */
+    CGH_EINVAL = -2,     /* bad argument (shape, alignment, NULL) */
+    CGH_ENOMEM = -3,     /* device or host allocation failed */
+    CGH_ENODEV = -4,     /* no usable GPU / library not initialised */
+    CGH_ECOMM = -5,      /* RCCL failure */
+    CGH_EINPUT = -6      /* malformed matrix (non-upper entry, row overflow): partial output kept, as the reference does */
+};
+
+/* ---- runtime ---------------------------------------------------------- */
+int         cgh_init(int device);          /* select device, create streams; idempotent for the same device */
+void        cgh_shutdown(void);
+int         cgh_device_count(void);
+const char *cgh_last_error(void);
+int         cgh_sync(void);                /* drain every stream the library owns */
+
+void *cgh_alloc(size_t bytes);             /* hipMalloc; NULL on failure */
+void  cgh_free(void *d_ptr);
+int   cgh_h2d(void *d_dst, const void *h_src, size_t bytes);
+int   cgh_d2h(void *h_dst, const void *d_src, size_t bytes);
+int   cgh_d2d(void *d_dst, const void *d_src, size_t bytes);
+int   cgh_memset(void *d_dst, int byte, size_t bytes);
+
+/* ---- matrices ----------------------------------------------------------
+ * A cgh_matrix is diag[n] plus the off-diagonals in one device layout.  In
+ * every layout a row's stored entries are kept in the ORDER in which the
+ * reference's SpMV for the source format accumulates them, so y = A x is
+ * bit-identical to the reference's (see DESIGN.md "Accumulation order").
+ */
+typedef struct cgh_matrix cgh_matrix;
+
+enum {
+    CGH_LAYOUT_ELL = 0,   /* slot-major full ELL: entry (row i, slot s) at s*n+i; pad = value 0.0, col -1 (reference ell.c:791-858 layout) */
+    CGH_LAYOUT_CSR = 1,   /* full (both triangles) CSR, int64 row_ptr, rows in reference accumulation order; vector/adaptive kernels */
+    CGH_LAYOUT_SELL = 2   /* sliced ELL: slices of 64 rows, each padded to its own width, slot-major inside the slice */
+};
+
+/* Host slot-major full ELL (what coo_to_ell_symmetric_full_colmajor produced) -> device. */
+cgh_matrix *cgh_matrix_from_ell_host(int64_t n, int K, const double *diag, const double *ell_vals, const int *ell_cols);
+/* Host upper-triangular COO/LDU triple (row-sorted or not) -> device conversion kernels -> `layout`.
+ * Slot / entry order inside a row is the reference's: rank of the placement among all earlier
+ * placements into that row, entry k placing (i,j) first and (j,i) second (reference ell.c:815-855). */
+cgh_matrix *cgh_matrix_from_coo_host(int64_t n, int64_t nnz_upper, const double *diag, const double *upper,
+                                     const int *rows, const int *cols, int layout);
+/* Same, inputs already on the device. */
+cgh_matrix *cgh_matrix_from_coo_device(int64_t n, int64_t nnz_upper, const double *d_diag, const double *d_upper,
+                                       const int *d_rows, const int *d_cols, int layout);
+/* Seeded synthetic SPD matrices generated on the device (DESIGN.md "Generators"); d_b (may be NULL) receives the rhs. */
+cgh_matrix *cgh_matrix_poisson(int nx, int ny, int nz, int points /*7|27*/, uint64_t seed, int layout, double *d_b);
+void        cgh_matrix_free(cgh_matrix *m);
+
+int64_t cgh_matrix_rows(const cgh_matrix *m);
+int     cgh_matrix_width(const cgh_matrix *m);        /* K: max off-diagonals per row */
+int64_t cgh_matrix_nnz_offdiag(const cgh_matrix *m);  /* stored non-pad off-diagonals (= 2U) */
+int     cgh_matrix_layout(const cgh_matrix *m);
+int64_t cgh_matrix_stored_bytes(const cgh_matrix *m); /* HBM bytes of the matrix arrays incl. padding */
+/* Download as slot-major full ELL of width K=cgh_matrix_width (any layout); buffers hold n*K entries. */
+int     cgh_matrix_download_ell(const cgh_matrix *m, double *ell_vals, int *ell_cols);
+int     cgh_matrix_download_diag(const cgh_matrix *m, double *diag);
+
+/* ---- kernels ------------------------------------------------------------ */
+int cgh_spmv(const cgh_matrix *m, const double *d_x, double *d_y);           /* y = A x */
+/* Fused BLAS-1 (device scalars are produced into d_out[0..]) */
+int cgh_dot(const double *d_a, const double *d_b, int64_t n, int strict, double *h_out);
+int cgh_l1norm(const double *d_a, int64_t n, int strict, double *h_out);
+int cgh_axpy(const double *d_a, const double *d_b, double alpha, double *d_out, int64_t n); /* out = a + alpha*b */
+
+/* ---- CG ------------------------------------------------------------------
+ * The loop of reference src/cg.c:414-508 with the matrix and all vectors
+ * resident: x=0; r=b; p=r; for iter=1..max_iter-1 { Ap=A p; alpha=rr/(p.Ap);
+ * x+=alpha p; r-=alpha Ap; rr'=r.r; if l1(r)/2<tol return iter+1;
+ * beta=rr'/rr; p=r+beta p }.  Returns the reference's value in report->ret.
+ */
+typedef struct cgh_cg_opts {
+    int    max_iter;      /* reference passes 1000 */
+    double tol;           /* reference passes 1e-6; compared with l1norm(r)/2 */
+    int    strict;        /* 1: dots/norms summed strictly left to right (bit-identical trajectory to the reference);
+                             0: wave-shuffle + LDS tree reductions (throughput) */
+    int    check_every;   /* iterations queued between host looks at the device's converged flag (>=1; 0 -> default 32).
+                             The device freezes x at the converging iteration, so the result does not depend on this. */
+    int    fixed_iters;   /* >0: run exactly this many iterations, never test convergence (benchmark mode) */
+    int    time_kernels;  /* 1: bracket the SpMV kernel of every iteration with HIP events (benchmark mode) */
+} cgh_cg_opts;
+
+typedef struct cgh_cg_report {
+    int    ret;           /* iter+1 on convergence, -1 otherwise (reference convention) */
+    int    iterations;    /* iterations executed */
+    double initial_res;   /* l1norm(r0)/2 */
+    double final_res;     /* l1norm(r)/2 after the last executed iteration */
+    double r0[5];         /* r[0..4] after r0 = b - A*0 (the reference prints them, cg.c:444-449) */
+    double solve_ms;      /* wall time of the iteration loop (HIP events) */
+    double spmv_ms_avg;   /* average SpMV kernel time when time_kernels=1, else 0 */
+} cgh_cg_report;
+
+/* h_history (may be NULL) receives 4 doubles per iteration k=0..iterations:
+ * { l1norm(r)/2, r.r, alpha, beta } (NaN where the reference computes none). Needs 4*max_iter doubles. */
+int cgh_cg_solve(const cgh_matrix *m, const double *d_b, double *d_x,
+                 const cgh_cg_opts *opts, cgh_cg_report *report, double *h_history);
+
+/* ---- timing helpers (benchmarks) ---------------------------------------- */
+/* Launch `reps` back-to-back SpMVs and return the average kernel time in ms (HIP events on the launch stream). */
+int cgh_time_spmv(const cgh_matrix *m, const double *d_x, double *d_y, int reps, double *ms_avg);
+/* float4-style device copy of `bytes` bytes, `reps` times: the attainable-HBM yardstick (ms per copy). */
+int cgh_time_copy(void *d_dst, const void *d_src, size_t bytes, int reps, double *ms_avg);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
