@@ -1,0 +1,176 @@
+#!/usr/bin/env python3
+"""bench.py -- CG iterations/s + SpMV HBM roofline on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload p7_256]
+
+A "step" is one CG iteration (SpMV + fused vector updates) on the workload matrix, resident
+in HBM.  N=1: synthetic 3-D 7-point Poisson 256^3 (16.7M rows, slot-major ELL), the configuration
+BASELINE.json quotes its target on.  N>1 (launched by torch.distributed.run, one rank per GPU): the
+SAME matrix row-block partitioned over the N GPUs (strong scaling, as north_star words its 8-GPU
+target), p-halo exchange and the two dot all-reduces over RCCL.
+
+Prints ONE JSON line (rank 0).  value = iterations/s of the whole job; roofline = the SpMV kernel
+(algorithmic bytes 12*nnz_off + 24*n per launch / its HIP-event time inside the timed region, vs
+8 TB/s HBM peak); cpu_baseline = the reference's own conjugate_gradient_ell_full_colmajor
+(oracle/_ref/libref.so, compiled from the reference sources) or, if that file is absent, this repo's
+CPU port (oracle/liboracle.so), timed on one host core on a bounded number of iterations of the same
+matrix.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+# libcg_hip first (binds /opt/rocm's HIP runtime); torch -- imported only for the multi-rank
+# rendezvous -- then finds libamdhip64.so.7 already loaded.
+import conjugate_gradient_amd as cga  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
+
+WORKLOADS = {
+    # name: (nx, ny, nz, points)
+    "p7_256": (256, 256, 256, 7),
+    "p7_128": (128, 128, 128, 7),
+    "p27_256": (256, 256, 256, 27),
+    "p27_512": (512, 512, 512, 27),
+}
+SEED = 0x5EED0001
+
+
+class quiet_stdout:
+    """The reference solver printf()s every iteration (cg.c:496); send C stdio to /dev/null meanwhile."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        C.CDLL(None).fflush(None)
+        self.saved = os.dup(1)
+        null = os.open(os.devnull, os.O_WRONLY)
+        os.dup2(null, 1)
+        os.close(null)
+
+    def __exit__(self, *a):
+        C.CDLL(None).fflush(None)
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+
+
+def cpu_baseline(A, b_dev, budget_s=15.0):
+    """Time the reference's CPU CG on the same matrix, 1 thread, bounded iterations."""
+    n, K = A.n, A.K
+    ev, ec = A.download_ell()
+    diag = A.download_diag()
+    b = b_dev.to_host()
+    x = np.zeros(n)
+    dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int)
+    D = lambda a: a.ctypes.data_as(dp)  # noqa: E731
+    I = lambda a: a.ctypes.data_as(ip)  # noqa: E731
+    ref_so = os.path.join(ROOT, "oracle", "_ref", "libref.so")
+    if os.path.exists(ref_so):
+        kind = "reference"
+        L = C.CDLL(ref_so)
+        spmv = lambda: L.mv_ell_symmetric_full_colmajor(n, K, D(diag), D(ev), I(ec), D(b), D(x))  # noqa: E731
+        L.conjugate_gradient_ell_full_colmajor.argtypes = [C.c_int, dp, C.c_int, dp, ip, C.c_int, dp, dp, C.c_int, C.c_double]
+        solve = lambda mi: L.conjugate_gradient_ell_full_colmajor(n, D(diag), int(A.nnz_offdiag // 2), D(ev), I(ec), K, D(b), D(x), mi, -1.0)  # noqa: E731
+    else:
+        import oracle_lib as O
+        kind = "port"
+        L = O.lib()
+        spmv = lambda: L.orc_mv_ell_symmetric_full_colmajor(n, K, D(diag), D(ev), I(ec), D(b), D(x))  # noqa: E731
+        solve = lambda mi: L.orc_cg(4, n, D(diag), 0, D(ev), I(ec), None, K, D(b), D(x), mi, -1.0, None)  # noqa: E731
+    t0 = time.perf_counter()
+    spmv()
+    t_spmv = time.perf_counter() - t0
+    iters = int(max(3, min(60, budget_s / (2.5 * t_spmv))))
+    with quiet_stdout():
+        t0 = time.perf_counter()
+        solve(iters + 1)   # the loop runs iter = 1 .. max_iter-1; tol = -1 never converges
+        dt = time.perf_counter() - t0
+    alg = 12 * A.nnz_offdiag + 24 * n
+    return {"value": iters / dt, "unit": "iterations/s", "cores": 1, "kind": kind,
+            "sample": "%d CG iterations of the same %d-row matrix (plus the set-up SpMV), 1 thread, %.1f s; "
+                      "its SpMV alone: %.3f s = %.2f GB/s algorithmic" % (iters, n, dt, t_spmv, alg / t_spmv / 1e9)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="p7_256", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`"
+                             % (args.gpus, args.gpus))
+        raise SystemExit("WORLD_SIZE=%d does not match --gpus %d" % (world, args.gpus))
+
+    nx, ny, nz, points = WORKLOADS[args.workload]
+    cga.init(local_rank)
+
+    if world > 1:
+        import bench_dist
+        return bench_dist.run(args, rank, world, local_rank, (nx, ny, nz, points), SEED)
+
+    n = nx * ny * nz
+    b = cga.DeviceVector(n)
+    x = cga.DeviceVector(n)
+    A = cga.Matrix.poisson(nx, ny, nz, points, SEED, cga.LAYOUT_ELL, b)
+    sv = cga.Solver(A, args.warmup + args.steps + 1)
+    sv.start(b, x, tol=-1.0, strict=0)          # tol < 0: never converges, every step does full work
+    sv.iterate(args.warmup, 0)
+    cga.check(cga.lib().cgh_sync())
+    t0 = time.perf_counter()
+    sv.iterate(args.steps, 1)                    # timed region: exactly K iterations, SpMV bracketed by HIP events
+    cga.check(cga.lib().cgh_sync())
+    dt = time.perf_counter() - t0
+    spmv_ms = sv.spmv_ms()
+    hist = sv.history(0, args.warmup + args.steps + 1)
+    assert np.all(np.isfinite(hist[1:, 0])), "non-finite residual: the iteration did not run"
+
+    alg_spmv = 12 * A.nnz_offdiag + 24 * n       # 12*nnz_off + 24*n per SpMV
+    achieved = alg_spmv / (spmv_ms * 1e-3) / 1e9
+    ms_step = dt / args.steps * 1e3
+    out = {
+        "metric": "CG iterations/sec (SpMV achieved HBM GB/s in roofline)",
+        "value": args.steps / dt,
+        "unit": "iterations/s",
+        "n_gpus": 1,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": ms_step,
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {"workload": "%s: 3-D %d-point Poisson %dx%dx%d, %d rows, slot-major ELL K=%d, unpreconditioned CG"
+                               % (args.workload, points, nx, ny, nz, n, A.K),
+                   "rows": n, "nnz_offdiag": int(A.nnz_offdiag), "parallelism": "1 GPU",
+                   "iter_bytes_algorithmic": int(12 * A.nnz_offdiag + 96 * n),
+                   "iter_GBs_algorithmic": (12 * A.nnz_offdiag + 96 * n) / (ms_step * 1e-3) / 1e9,
+                   "residual_l1_half_first_last": [float(hist[0, 0]), float(hist[-1, 0])]},
+        "roofline": {"bound": "hbm", "kernel": "spmv_ell_r2 (SpMV + p.Ap partials)", "achieved": achieved,
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "bytes_per_launch": int(alg_spmv), "ms_per_launch": spmv_ms, "traffic": None},
+    }
+    if not args.no_cpu_baseline:
+        sv.free()
+        out["cpu_baseline"] = cpu_baseline(A, b)
+    print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -5,4 +5,5 @@ This package is only the ctypes view of that ABI used by tests/ and bench.py;
 it carries no compute of its own and raises if the library or a GPU is missing.
 """
 from .binding import (CgOpts, CgReport, DeviceVector, Matrix, lib, init, have_gpu,  # noqa: F401
-                      LAYOUT_ELL, LAYOUT_CSR, LAYOUT_SELL, LIB_PATH, cg_solve)
+                      LAYOUT_ELL, LAYOUT_CSR, LAYOUT_SELL, LIB_PATH, cg_solve, Solver, check)
+from . import binding  # noqa: F401

@@ -71,6 +71,17 @@ def lib():
     L.cgh_l1norm.argtypes = [vp, i64, C.c_int, dp]
     L.cgh_axpy.argtypes = [vp, vp, C.c_double, vp, i64]
     L.cgh_cg_solve.argtypes = [vp, vp, vp, C.POINTER(CgOpts), C.POINTER(CgReport), dp]
+    L.cgh_solver_create.argtypes = [vp, C.c_int]
+    L.cgh_solver_create.restype = vp
+    L.cgh_solver_free.argtypes = [vp]
+    L.cgh_solver_free.restype = None
+    L.cgh_solver_start.argtypes = [vp, vp, vp, C.c_double, C.c_int]
+    L.cgh_solver_iterate.argtypes = [vp, C.c_int, C.c_int]
+    L.cgh_solver_poll.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.cgh_solver_history.argtypes = [vp, C.c_int, C.c_int, dp]
+    L.cgh_solver_spmv_ms.argtypes = [vp, dp]
+    L.cgh_solver_residual.argtypes = [vp]
+    L.cgh_solver_residual.restype = vp
     L.cgh_time_spmv.argtypes = [vp, vp, vp, C.c_int, dp]
     L.cgh_time_copy.argtypes = [vp, vp, C.c_size_t, C.c_int, dp]
     _lib = L
@@ -201,3 +212,46 @@ def cg_solve(mat, b, x, max_iter=1000, tol=1e-6, strict=0, check_every=0, fixed_
     check(lib().cgh_cg_solve(mat.h, b.ptr, x.ptr, C.byref(opts), C.byref(rep),
                              _D(hist) if history else None), "cgh_cg_solve")
     return rep, (hist[:rep.iterations + 1] if history else None)
+
+
+class Solver:
+    """Resumable device CG (cgh_solver_*): queue iterations in batches, poll when you choose."""
+
+    def __init__(self, mat, capacity):
+        self.mat = mat
+        self.h = lib().cgh_solver_create(mat.h, capacity)
+        if not self.h:
+            raise RuntimeError("cgh_solver_create failed: " + lib().cgh_last_error().decode())
+
+    def start(self, b, x, tol=1e-6, strict=0):
+        self._keep = (b, x)
+        check(lib().cgh_solver_start(self.h, b.ptr, x.ptr, tol, strict), "cgh_solver_start")
+
+    def iterate(self, count, time_kernels=0):
+        check(lib().cgh_solver_iterate(self.h, count, time_kernels), "cgh_solver_iterate")
+
+    def poll(self):
+        d, q = C.c_int(), C.c_int()
+        check(lib().cgh_solver_poll(self.h, C.byref(d), C.byref(q)), "cgh_solver_poll")
+        return d.value, q.value
+
+    def history(self, first, count):
+        out = np.empty((count, 4))
+        check(lib().cgh_solver_history(self.h, first, count, _D(out)), "cgh_solver_history")
+        return out
+
+    def spmv_ms(self):
+        v = C.c_double()
+        check(lib().cgh_solver_spmv_ms(self.h, C.byref(v)), "cgh_solver_spmv_ms")
+        return v.value
+
+    def free(self):
+        if self.h:
+            lib().cgh_solver_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass

@@ -31,6 +31,33 @@ namespace {
 
 constexpr int HIST = 4;  // doubles per history entry: res, rr, alpha, beta
 
+typedef double d2_t __attribute__((ext_vector_type(2)));
+
+// Streaming accesses: every vector here is far larger than L2 and touched once per kernel, so loads and
+// stores are non-temporal (measured +15 % on the SpMV's y store, profiles/).  VV bit0 = nt loads, bit1 = nt stores.
+template <int VV>
+__device__ __forceinline__ double2 ld2(const double *p, int64_t k)
+{
+    if constexpr (VV & 1) {
+        const d2_t v = __builtin_nontemporal_load(reinterpret_cast<const d2_t *>(p) + k);
+        return make_double2(v.x, v.y);
+    } else {
+        return reinterpret_cast<const double2 *>(p)[k];
+    }
+}
+template <int VV>
+__device__ __forceinline__ void st2(double *p, int64_t k, double a, double b)
+{
+    if constexpr (VV & 2) {
+        d2_t v;
+        v.x = a;
+        v.y = b;
+        __builtin_nontemporal_store(v, reinterpret_cast<d2_t *>(p) + k);
+    } else {
+        reinterpret_cast<double2 *>(p)[k] = make_double2(a, b);
+    }
+}
+
 // ---------------------------------------------------------------- tree-mode kernels
 
 // r = b - Ap0 (Ap0 = A*0 computed by the SpMV, as the reference does), p = r; partials of r.r, |r|_1
@@ -69,12 +96,12 @@ __global__ __launch_bounds__(CGH_BLOCK) void cg_finish_init(const double *__rest
 }
 
 // K2.  VEC2: n even and 16-B aligned vectors.
-template <bool STRICT>
+template <bool STRICT, int VV>
 __global__ __launch_bounds__(CGH_BLOCK) void cg_update_xr(int64_t n, double *__restrict__ x, const double *__restrict__ p,
                                                          double *__restrict__ r, const double *__restrict__ Ap,
                                                          const double *__restrict__ pAp_partials, int pAp_count,
                                                          double *__restrict__ out_partials, double *hist, int iter,
-                                                         const int *__restrict__ done)
+                                                         const int *__restrict__ done, int rev)
 {
     __shared__ double lds[4];
     if (*done != 0) return;
@@ -89,16 +116,19 @@ __global__ __launch_bounds__(CGH_BLOCK) void cg_update_xr(int64_t n, double *__r
     const double nalpha = -alpha;
     double       rr = 0.0, l1 = 0.0;
     const int64_t pairs = n >> 1;
-    for (int64_t k = (int64_t)blockIdx.x * CGH_BLOCK + threadIdx.x; k < pairs; k += (int64_t)gridDim.x * CGH_BLOCK) {
-        const double2 xv = reinterpret_cast<const double2 *>(x)[k];
-        const double2 pv = reinterpret_cast<const double2 *>(p)[k];
-        const double2 rv = reinterpret_cast<const double2 *>(r)[k];
-        const double2 av = reinterpret_cast<const double2 *>(Ap)[k];
+    const int64_t chunks = (pairs + CGH_BLOCK - 1) / CGH_BLOCK;
+    for (int64_t cc = blockIdx.x; cc < chunks; cc += gridDim.x) {
+        const int64_t k = (rev ? chunks - 1 - cc : cc) * CGH_BLOCK + threadIdx.x;
+        if (k >= pairs) continue;
+        const double2 xv = ld2<VV>(x, k);
+        const double2 pv = ld2<VV>(p, k);
+        const double2 rv = ld2<VV>(r, k);
+        const double2 av = ld2<VV>(Ap, k);
         // reference vec_axpy: out = a + alpha*b (vec.c:88-94), called with alpha and -alpha (cg.c:467,469)
         const double2 xn = make_double2(madd_rn(xv.x, alpha, pv.x), madd_rn(xv.y, alpha, pv.y));
         const double2 rn = make_double2(madd_rn(rv.x, nalpha, av.x), madd_rn(rv.y, nalpha, av.y));
-        reinterpret_cast<double2 *>(x)[k] = xn;
-        reinterpret_cast<double2 *>(r)[k] = rn;
+        st2<VV>(x, k, xn.x, xn.y);
+        st2<VV>(r, k, rn.x, rn.y);
         if constexpr (!STRICT) {
             rr += rn.x * rn.x + rn.y * rn.y;
             l1 += fabs(rn.x) + fabs(rn.y);
@@ -126,10 +156,10 @@ __global__ __launch_bounds__(CGH_BLOCK) void cg_update_xr(int64_t n, double *__r
 }
 
 // K3.
-template <bool STRICT>
+template <bool STRICT, int VV>
 __global__ __launch_bounds__(CGH_BLOCK) void cg_update_p(int64_t n, const double *__restrict__ r, double *__restrict__ p,
                                                         const double *__restrict__ partials, int count, double *hist,
-                                                        int iter, double tol, int *done)
+                                                        int iter, double tol, int *done, int rev)
 {
     __shared__ double lds[4];
     if (*done != 0) return;
@@ -158,10 +188,13 @@ __global__ __launch_bounds__(CGH_BLOCK) void cg_update_p(int64_t n, const double
         return;
     }
     const int64_t pairs = n >> 1;
-    for (int64_t k = (int64_t)blockIdx.x * CGH_BLOCK + threadIdx.x; k < pairs; k += (int64_t)gridDim.x * CGH_BLOCK) {
-        const double2 rv = reinterpret_cast<const double2 *>(r)[k];
-        const double2 pv = reinterpret_cast<const double2 *>(p)[k];
-        reinterpret_cast<double2 *>(p)[k] = make_double2(madd_rn(rv.x, beta, pv.x), madd_rn(rv.y, beta, pv.y));
+    const int64_t chunks = (pairs + CGH_BLOCK - 1) / CGH_BLOCK;
+    for (int64_t cc = blockIdx.x; cc < chunks; cc += gridDim.x) {
+        const int64_t k = (rev ? chunks - 1 - cc : cc) * CGH_BLOCK + threadIdx.x;
+        if (k >= pairs) continue;
+        const double2 rv = ld2<VV>(r, k);
+        const double2 pv = ld2<VV>(p, k);
+        st2<VV>(p, k, madd_rn(rv.x, beta, pv.x), madd_rn(rv.y, beta, pv.y));
     }
     if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) p[n - 1] = madd_rn(r[n - 1], beta, p[n - 1]);
 }
@@ -292,6 +325,21 @@ int reduce_pair(const double *a, const double *b, const double *c, int64_t n, in
 
 } // namespace
 
+struct cgh_solver {
+    const cgh_matrix *m = nullptr;
+    int64_t           n = 0;
+    int               capacity = 0;   // iterations the history can hold
+    int               queued = 0;     // iterations queued since start
+    int               vgrid = 0;
+    bool              strict = false;
+    double            tol = 0.0;
+    double           *x = nullptr;    // caller's solution vector
+    double           *r = nullptr, *p = nullptr, *Ap = nullptr;
+    double           *partA = nullptr, *partB = nullptr, *hist = nullptr;
+    int              *done = nullptr;
+    std::vector<hipEvent_t> kev;      // SpMV kernel brackets (time_kernels)
+};
+
 extern "C" {
 
 int cgh_dot(const double *d_a, const double *d_b, int64_t n, int strict, double *h_out)
@@ -328,6 +376,187 @@ int cgh_axpy(const double *d_a, const double *d_b, double alpha, double *d_out, 
     return CGH_OK;
 }
 
+cgh_solver *cgh_solver_create(const cgh_matrix *m, int capacity)
+{
+    CGH_REQUIRE_READY(nullptr);
+    if (!m || m->n <= 0 || capacity < 1) {
+        cgh_set_error("cgh_solver_create: bad arguments");
+        return nullptr;
+    }
+    cgh_solver *sv = new cgh_solver();
+    sv->m = m;
+    sv->n = m->n;
+    sv->capacity = capacity;
+    const size_t vbytes = sizeof(double) * (size_t)m->n;
+    sv->r = (double *)cgh_alloc(vbytes);
+    sv->p = (double *)cgh_alloc(vbytes);
+    sv->Ap = (double *)cgh_alloc(vbytes);
+    sv->partA = (double *)cgh_alloc(sizeof(double) * CGH_MAX_PARTIALS);
+    sv->partB = (double *)cgh_alloc(sizeof(double) * 2 * CGH_MAX_PARTIALS);
+    sv->hist = (double *)cgh_alloc(sizeof(double) * HIST * (size_t)(capacity + 1));
+    sv->done = (int *)cgh_alloc(sizeof(int) * 4);
+    sv->vgrid = vec_grid(m->n);
+    if (!sv->r || !sv->p || !sv->Ap || !sv->partA || !sv->partB || !sv->hist || !sv->done) {
+        cgh_solver_free(sv);
+        return nullptr;
+    }
+    return sv;
+}
+
+void cgh_solver_free(cgh_solver *sv)
+{
+    if (!sv) return;
+    for (hipEvent_t e : sv->kev) (void)hipEventDestroy(e);
+    cgh_free(sv->r);
+    cgh_free(sv->p);
+    cgh_free(sv->Ap);
+    cgh_free(sv->partA);
+    cgh_free(sv->partB);
+    cgh_free(sv->hist);
+    cgh_free(sv->done);
+    delete sv;
+}
+
+// x = 0; r = b - A x; p = r; rr = r.r (reference cg.c:433-456).  Asynchronous.
+int cgh_solver_start(cgh_solver *sv, const double *d_b, double *d_x, double tol, int strict)
+{
+    CGH_REQUIRE_READY(CGH_ENODEV);
+    if (!sv || !d_b || !d_x) {
+        cgh_set_error("cgh_solver_start: NULL argument");
+        return CGH_EINVAL;
+    }
+    if ((reinterpret_cast<uintptr_t>(d_b) | reinterpret_cast<uintptr_t>(d_x)) & 15u) {
+        cgh_set_error("cgh_solver_start: d_b and d_x must be 16-byte aligned");
+        return CGH_EINVAL;
+    }
+    hipStream_t   s = g_cgh.stream;
+    const int64_t n = sv->n;
+    sv->x = d_x;
+    sv->tol = tol;
+    sv->strict = strict != 0;
+    sv->queued = 0;
+    for (hipEvent_t e : sv->kev) (void)hipEventDestroy(e);
+    sv->kev.clear();
+    CGH_HIP(hipMemsetAsync(sv->done, 0, sizeof(int) * 4, s));
+    CGH_HIP(hipMemsetAsync(d_x, 0, sizeof(double) * (size_t)n, s));
+    int rc = cgh_launch_spmv(sv->m, d_x, sv->Ap, nullptr, nullptr, nullptr, s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(cg_init_rp, dim3(sv->vgrid), dim3(CGH_BLOCK), 0, s, n, d_b, (const double *)sv->Ap, sv->r, sv->p,
+                       sv->partB);
+    if (sv->strict)
+        hipLaunchKernelGGL(seq_sums, dim3(1), dim3(CGH_BLOCK), 0, s, n, (const double *)sv->r, (const double *)sv->r,
+                           (const double *)sv->r, 3, sv->hist, 0, tol, sv->done, (double *)nullptr);
+    else
+        hipLaunchKernelGGL(cg_finish_init, dim3(1), dim3(CGH_BLOCK), 0, s, (const double *)sv->partB, sv->vgrid, sv->hist);
+    CGH_HIP(hipGetLastError());
+    return CGH_OK;
+}
+
+// Queue `count` more iterations on the compute stream (no host synchronisation).
+int cgh_solver_iterate(cgh_solver *sv, int count, int time_kernels)
+{
+    CGH_REQUIRE_READY(CGH_ENODEV);
+    if (!sv || count < 0 || sv->queued + count > sv->capacity) {
+        cgh_set_error("cgh_solver_iterate: count %d exceeds the solver's capacity", count);
+        return CGH_EINVAL;
+    }
+    hipStream_t   s = g_cgh.stream;
+    const int64_t n = sv->n;
+    const int     vg = sv->vgrid;
+    double       *dr = sv->r, *dp = sv->p, *dAp = sv->Ap, *dA = sv->partA, *dB = sv->partB, *dh = sv->hist, *d_x = sv->x;
+    int          *dd = sv->done;
+    const double  tol = sv->tol;
+    for (int c = 0; c < count; ++c) {
+        const int iter = ++sv->queued;
+        int       gridA = 0;
+        // serpentine sweeps: each kernel starts where the previous one ended, so the tail of what was just
+        // written/read could still be in the 256 MiB Infinity Cache.  Measured null on MI355X (0.4791 vs 0.4797
+        // ms/iter, 256^3), so off by default; env CGH_SERPENTINE=1 enables it for experiments.
+        static const int serp = getenv("CGH_SERPENTINE") ? atoi(getenv("CGH_SERPENTINE")) : 0;
+        const int        rev1 = serp ? (iter & 1) : 0, rev2 = serp ? !rev1 : 0;
+        g_cgh.sweep_reverse = rev1;
+        if (time_kernels) {
+            hipEvent_t a, b;
+            CGH_HIP(hipEventCreate(&a));
+            CGH_HIP(hipEventCreate(&b));
+            sv->kev.push_back(a);
+            sv->kev.push_back(b);
+            CGH_HIP(hipEventRecord(a, s));
+        }
+        int rc = cgh_launch_spmv(sv->m, dp, dAp, sv->strict ? nullptr : dA, &gridA, dd, s);
+        if (rc) return rc;
+        g_cgh.sweep_reverse = 0;
+        if (time_kernels) CGH_HIP(hipEventRecord(sv->kev.back(), s));
+        if (sv->strict) {
+            hipLaunchKernelGGL(seq_sums, dim3(1), dim3(CGH_BLOCK), 0, s, n, (const double *)dp, (const double *)dAp,
+                               (const double *)nullptr, 1, dh, iter, tol, dd, (double *)nullptr);
+            hipLaunchKernelGGL((cg_update_xr<true, 3>), dim3(vg), dim3(CGH_BLOCK), 0, s, n, d_x, (const double *)dp, dr,
+                               (const double *)dAp, (const double *)dA, gridA, dB, dh, iter, (const int *)dd, rev2);
+            hipLaunchKernelGGL(seq_sums, dim3(1), dim3(CGH_BLOCK), 0, s, n, (const double *)dr, (const double *)dr,
+                               (const double *)dr, 2, dh, iter, tol, dd, (double *)nullptr);
+            hipLaunchKernelGGL((cg_update_p<true, 3>), dim3(vg), dim3(CGH_BLOCK), 0, s, n, (const double *)dr, dp,
+                               (const double *)dB, vg, dh, iter, tol, dd, rev1);
+        } else {
+            static const int vv = getenv("CGH_VEC_VARIANT") ? atoi(getenv("CGH_VEC_VARIANT")) & 3 : 3;
+#define CGH_VEC_VAR(V)                                                                                                 \
+    case V:                                                                                                            \
+        hipLaunchKernelGGL((cg_update_xr<false, V>), dim3(vg), dim3(CGH_BLOCK), 0, s, n, d_x, (const double *)dp, dr,  \
+                           (const double *)dAp, (const double *)dA, gridA, dB, dh, iter, (const int *)dd, rev2);             \
+        hipLaunchKernelGGL((cg_update_p<false, V>), dim3(vg), dim3(CGH_BLOCK), 0, s, n, (const double *)dr, dp,        \
+                           (const double *)dB, vg, dh, iter, tol, dd, rev1);                                                 \
+        break;
+            switch (vv) {
+                CGH_VEC_VAR(0)
+                CGH_VEC_VAR(1)
+                CGH_VEC_VAR(2)
+                CGH_VEC_VAR(3)
+            }
+#undef CGH_VEC_VAR
+        }
+    }
+    CGH_HIP(hipGetLastError());
+    return CGH_OK;
+}
+
+// Drain the stream and read the device's verdict: *done_iter = converging iteration (0 = not yet).
+int cgh_solver_poll(cgh_solver *sv, int *done_iter, int *queued)
+{
+    CGH_REQUIRE_READY(CGH_ENODEV);
+    if (!sv) return CGH_EINVAL;
+    int d = 0;
+    CGH_HIP(hipMemcpyAsync(&d, sv->done, sizeof(int), hipMemcpyDeviceToHost, g_cgh.stream));
+    CGH_HIP(hipStreamSynchronize(g_cgh.stream));
+    if (done_iter) *done_iter = d;
+    if (queued) *queued = sv->queued;
+    return CGH_OK;
+}
+
+// Copy history entries [first, first+count) (4 doubles each) to the host; synchronises.
+int cgh_solver_history(cgh_solver *sv, int first, int count, double *h_out)
+{
+    CGH_REQUIRE_READY(CGH_ENODEV);
+    if (!sv || first < 0 || count < 0 || first + count > sv->capacity + 1) return CGH_EINVAL;
+    return cgh_d2h(h_out, sv->hist + (size_t)first * HIST, sizeof(double) * HIST * (size_t)count);
+}
+
+// Average SpMV kernel time (ms) over the iterations queued with time_kernels=1 since start; synchronises.
+int cgh_solver_spmv_ms(cgh_solver *sv, double *ms_avg)
+{
+    CGH_REQUIRE_READY(CGH_ENODEV);
+    if (!sv || !ms_avg) return CGH_EINVAL;
+    CGH_HIP(hipStreamSynchronize(g_cgh.stream));
+    double tot = 0.0;
+    for (size_t k = 0; k + 1 < sv->kev.size(); k += 2) {
+        float t = 0.f;
+        CGH_HIP(hipEventElapsedTime(&t, sv->kev[k], sv->kev[k + 1]));
+        tot += t;
+    }
+    *ms_avg = sv->kev.empty() ? 0.0 : tot / (double)(sv->kev.size() / 2);
+    return CGH_OK;
+}
+
+const double *cgh_solver_residual(const cgh_solver *sv) { return sv ? sv->r : nullptr; }
+
 int cgh_cg_solve(const cgh_matrix *m, const double *d_b, double *d_x, const cgh_cg_opts *opts, cgh_cg_report *rep,
                  double *h_history)
 {
@@ -336,117 +565,59 @@ int cgh_cg_solve(const cgh_matrix *m, const double *d_b, double *d_x, const cgh_
         cgh_set_error("cgh_cg_solve: NULL argument");
         return CGH_EINVAL;
     }
-    const int64_t n = m->n;
-    const bool    strict = opts->strict != 0;
-    const bool    fixed = opts->fixed_iters > 0;
-    const int     max_iter = fixed ? opts->fixed_iters + 1 : opts->max_iter;
-    const double  tol = fixed ? -1.0 : opts->tol;  // l1/2 >= 0 is never < -1: no convergence in benchmark mode
-    int           check = opts->check_every > 0 ? opts->check_every : 32;
+    const bool   fixed = opts->fixed_iters > 0;
+    const int    max_iter = fixed ? opts->fixed_iters + 1 : opts->max_iter;
+    const double tol = fixed ? -1.0 : opts->tol;  // l1/2 >= 0 is never < -1: no convergence in benchmark mode
+    const int    check = opts->check_every > 0 ? opts->check_every : 32;
     memset(rep, 0, sizeof *rep);
     rep->ret = -1;
-    if (n <= 0 || max_iter < 1) {
-        cgh_set_error("cgh_cg_solve: n=%lld max_iter=%d", (long long)n, max_iter);
+    if (m->n <= 0 || max_iter < 1) {
+        cgh_set_error("cgh_cg_solve: n=%lld max_iter=%d", (long long)m->n, max_iter);
         return CGH_EINVAL;
     }
-    if ((reinterpret_cast<uintptr_t>(d_b) | reinterpret_cast<uintptr_t>(d_x)) & 15u) {
-        cgh_set_error("cgh_cg_solve: d_b and d_x must be 16-byte aligned");
-        return CGH_EINVAL;
-    }
-
+    cgh_solver *sv = cgh_solver_create(m, max_iter);
+    if (!sv) return CGH_ENOMEM;
+    struct guard {
+        cgh_solver *p;
+        ~guard() { cgh_solver_free(p); }
+    } g{sv};
     hipStream_t s = g_cgh.stream;
-    const size_t vbytes = sizeof(double) * (size_t)n;
-    scratch_buf  r(vbytes), p(vbytes), Ap(vbytes);
-    scratch_buf  partA(sizeof(double) * CGH_MAX_PARTIALS), partB(sizeof(double) * 2 * CGH_MAX_PARTIALS);
-    scratch_buf  hist(sizeof(double) * HIST * (size_t)(max_iter + 1)), done(sizeof(int) * 4);
-    if (!r.p || !p.p || !Ap.p || !partA.p || !partB.p || !hist.p || !done.p) return CGH_ENOMEM;
-    double *dr = (double *)r.p, *dp = (double *)p.p, *dAp = (double *)Ap.p;
-    double *dA = (double *)partA.p, *dB = (double *)partB.p, *dh = (double *)hist.p;
-    int    *dd = (int *)done.p;
-    const int vg = vec_grid(n);
-
-    // ---- setup: x = 0; r = b - A x; p = r; rr = r.r (cg.c:433-456)
-    CGH_HIP(hipMemsetAsync(dd, 0, sizeof(int) * 4, s));
-    CGH_HIP(hipMemsetAsync(d_x, 0, vbytes, s));
-    int rc = cgh_launch_spmv(m, d_x, dAp, nullptr, nullptr, nullptr, s);
+    int         rc = cgh_solver_start(sv, d_b, d_x, tol, opts->strict);
     if (rc) return rc;
-    hipLaunchKernelGGL(cg_init_rp, dim3(vg), dim3(CGH_BLOCK), 0, s, n, d_b, (const double *)dAp, dr, dp, dB);
-    if (strict)
-        hipLaunchKernelGGL(seq_sums, dim3(1), dim3(CGH_BLOCK), 0, s, n, (const double *)dr, (const double *)dr,
-                           (const double *)dr, 3, dh, 0, tol, dd, (double *)nullptr);
-    else
-        hipLaunchKernelGGL(cg_finish_init, dim3(1), dim3(CGH_BLOCK), 0, s, (const double *)dB, vg, dh);
-    CGH_HIP(hipGetLastError());
-    CGH_HIP(hipMemcpyAsync(rep->r0, dr, sizeof(double) * (n < 5 ? n : 5), hipMemcpyDeviceToHost, s));
+    CGH_HIP(hipMemcpyAsync(rep->r0, sv->r, sizeof(double) * (m->n < 5 ? m->n : 5), hipMemcpyDeviceToHost, s));
 
-    // ---- iterations
     hipEvent_t ev0, ev1;
     CGH_HIP(hipEventCreate(&ev0));
     CGH_HIP(hipEventCreate(&ev1));
-    std::vector<hipEvent_t> kev;
-    const bool              timek = opts->time_kernels != 0;
     CGH_HIP(hipEventRecord(ev0, s));
-    int done_iter = 0, launched = 0;
-    for (int iter = 1; iter < max_iter && done_iter == 0; ++iter) {
-        int gridA = 0;
-        if (timek) {
-            hipEvent_t a, b;
-            CGH_HIP(hipEventCreate(&a));
-            CGH_HIP(hipEventCreate(&b));
-            kev.push_back(a);
-            kev.push_back(b);
-            CGH_HIP(hipEventRecord(a, s));
-        }
-        rc = cgh_launch_spmv(m, dp, dAp, strict ? nullptr : dA, &gridA, dd, s);
+    int done_iter = 0;
+    const int total = max_iter - 1;  // reference loop: iter = 1 .. max_iter-1 (cg.c:459)
+    while (sv->queued < total && done_iter == 0) {
+        int chunk = total - sv->queued;
+        if (!fixed && chunk > check) chunk = check;
+        rc = cgh_solver_iterate(sv, chunk, opts->time_kernels);
         if (rc) return rc;
-        if (timek) CGH_HIP(hipEventRecord(kev.back(), s));
-        if (strict) {
-            hipLaunchKernelGGL(seq_sums, dim3(1), dim3(CGH_BLOCK), 0, s, n, (const double *)dp, (const double *)dAp,
-                               (const double *)nullptr, 1, dh, iter, tol, dd, (double *)nullptr);
-            hipLaunchKernelGGL((cg_update_xr<true>), dim3(vg), dim3(CGH_BLOCK), 0, s, n, d_x, (const double *)dp, dr,
-                               (const double *)dAp, (const double *)dA, gridA, dB, dh, iter, (const int *)dd);
-            hipLaunchKernelGGL(seq_sums, dim3(1), dim3(CGH_BLOCK), 0, s, n, (const double *)dr, (const double *)dr,
-                               (const double *)dr, 2, dh, iter, tol, dd, (double *)nullptr);
-            hipLaunchKernelGGL((cg_update_p<true>), dim3(vg), dim3(CGH_BLOCK), 0, s, n, (const double *)dr, dp,
-                               (const double *)dB, vg, dh, iter, tol, dd);
-        } else {
-            hipLaunchKernelGGL((cg_update_xr<false>), dim3(vg), dim3(CGH_BLOCK), 0, s, n, d_x, (const double *)dp, dr,
-                               (const double *)dAp, (const double *)dA, gridA, dB, dh, iter, (const int *)dd);
-            hipLaunchKernelGGL((cg_update_p<false>), dim3(vg), dim3(CGH_BLOCK), 0, s, n, (const double *)dr, dp,
-                               (const double *)dB, vg, dh, iter, tol, dd);
-        }
-        launched = iter;
-        if (!fixed && (iter % check == 0 || iter == max_iter - 1)) {
-            CGH_HIP(hipGetLastError());
-            CGH_HIP(hipMemcpyAsync(&done_iter, dd, sizeof(int), hipMemcpyDeviceToHost, s));
-            CGH_HIP(hipStreamSynchronize(s));
+        if (!fixed) {
+            rc = cgh_solver_poll(sv, &done_iter, nullptr);
+            if (rc) return rc;
         }
     }
-    CGH_HIP(hipGetLastError());
     CGH_HIP(hipEventRecord(ev1, s));
-    CGH_HIP(hipMemcpyAsync(&done_iter, dd, sizeof(int), hipMemcpyDeviceToHost, s));
-    CGH_HIP(hipStreamSynchronize(s));
+    rc = cgh_solver_poll(sv, &done_iter, nullptr);
+    if (rc) return rc;
     float ms = 0.f;
     CGH_HIP(hipEventElapsedTime(&ms, ev0, ev1));
-    rep->solve_ms = ms;
-    if (timek) {
-        double tot = 0.0;
-        for (size_t k = 0; k + 1 < kev.size(); k += 2) {
-            float t = 0.f;
-            CGH_HIP(hipEventElapsedTime(&t, kev[k], kev[k + 1]));
-            tot += t;
-        }
-        rep->spmv_ms_avg = kev.empty() ? 0.0 : tot / (double)(kev.size() / 2);
-        for (hipEvent_t e : kev) (void)hipEventDestroy(e);
-    }
     (void)hipEventDestroy(ev0);
     (void)hipEventDestroy(ev1);
+    rep->solve_ms = ms;
+    if (opts->time_kernels) cgh_solver_spmv_ms(sv, &rep->spmv_ms_avg);
 
-    const int executed = done_iter ? done_iter : launched;
+    const int executed = done_iter ? done_iter : sv->queued;
     rep->iterations = executed;
     rep->ret = done_iter ? done_iter + 1 : -1;
     std::vector<double> hh((size_t)HIST * (executed + 1));
-    CGH_HIP(hipMemcpyAsync(hh.data(), dh, hh.size() * sizeof(double), hipMemcpyDeviceToHost, s));
-    CGH_HIP(hipStreamSynchronize(s));
+    rc = cgh_solver_history(sv, 0, executed + 1, hh.data());
+    if (rc) return rc;
     rep->initial_res = hh[0];
     rep->final_res = hh[(size_t)HIST * executed];
     if (h_history) memcpy(h_history, hh.data(), hh.size() * sizeof(double));

@@ -16,6 +16,7 @@ struct cgh_context {
     int         num_cu = 256;
     hipStream_t stream = nullptr;       // compute stream: every kernel of the solver
     hipStream_t comm_stream = nullptr;  // halo exchange / collectives (multi-GPU)
+    int         sweep_reverse = 0;      // 1: the next launches walk their arrays from the end (serpentine sweeps)
     char        err[512] = {0};
 };
 extern cgh_context g_cgh;

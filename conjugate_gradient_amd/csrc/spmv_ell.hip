@@ -24,21 +24,25 @@ typedef int    i2_t __attribute__((ext_vector_type(2)));
 
 // Matrix values/columns are read exactly once per SpMV: non-temporal loads keep them from
 // displacing the gathered x lines in L2.
-template <typename T>
+template <bool NT, typename T>
 __device__ __forceinline__ T stream_load(const T *p)
 {
-#ifdef CGH_NO_NT
-    return *p;
-#else
-    return __builtin_nontemporal_load(p);
-#endif
+    if constexpr (NT)
+        return __builtin_nontemporal_load(p);
+    else
+        return *p;
 }
 
-template <int KT, bool DOT>
+// Tuning variants (env CGH_ELL_VARIANT, default = the shipped one): bit0 = XCD-chunked tile walk,
+// bit1 = non-temporal matrix loads, bit2 = ablation (no gather; wrong results), bit3 = non-temporal y store.
+constexpr int VAR_DEFAULT = 11;
+
+template <int KT, bool DOT, int VAR>
 __global__ __launch_bounds__(CGH_BLOCK) void spmv_ell_r2(int64_t n, int Krt, const double *__restrict__ diag,
                                                         const double *__restrict__ vals, const int *__restrict__ cols,
                                                         const double *__restrict__ x, double *__restrict__ y,
-                                                        double *__restrict__ partials, const int *__restrict__ done)
+                                                        double *__restrict__ partials, const int *__restrict__ done,
+                                                        int rev)
 {
     __shared__ double lds[4];
     if (done != nullptr && *done != 0) return;
@@ -46,7 +50,20 @@ __global__ __launch_bounds__(CGH_BLOCK) void spmv_ell_r2(int64_t n, int Krt, con
     const int64_t pairs = n >> 1;  // n is even on this path
     double        local = 0.0;
 
-    for (int64_t pr = (int64_t)blockIdx.x * CGH_BLOCK + threadIdx.x; pr < pairs; pr += (int64_t)gridDim.x * CGH_BLOCK) {
+    // Tile walk.  Workgroup-iteration j (= blockIdx + k*gridDim, gridDim a multiple of 8) runs on XCD
+    // group j%8.  Tiles are dealt to XCD groups in chunks of 8 consecutive tiles (4096 rows):
+    // t = 64*(q/8) + 8*(j%8) + q%8 with q = j/8, a bijection on every aligned group of 64 tiles.  A row's
+    // +-1 / +-nx neighbours then almost always belong to the same XCD's chunk, so each x line is fetched
+    // into one L2 instead of two or three (measured: SpMV FETCH_SIZE, profiles/).
+    const int64_t tiles = (pairs + CGH_BLOCK - 1) / CGH_BLOCK;
+    const int64_t tiles64 = (tiles + 63) & ~(int64_t)63;
+    constexpr bool REMAP = (VAR & 1) != 0, NT = (VAR & 2) != 0, NOGATHER = (VAR & 4) != 0, NTSTORE = (VAR & 8) != 0;
+    for (int64_t jj = blockIdx.x; jj < tiles64; jj += gridDim.x) {
+        const int64_t j = rev ? tiles64 - 1 - jj : jj;
+        const int64_t q = j >> 3;
+        const int64_t t = REMAP ? ((q >> 3) << 6) + ((j & 7) << 3) + (q & 7) : j;
+        const int64_t pr = t * CGH_BLOCK + threadIdx.x;
+        if (pr >= pairs) continue;
         const int64_t i0 = pr << 1;
         const double2 d = *reinterpret_cast<const double2 *>(diag + i0);
         const double2 xi = *reinterpret_cast<const double2 *>(x + i0);
@@ -57,14 +74,19 @@ __global__ __launch_bounds__(CGH_BLOCK) void spmv_ell_r2(int64_t n, int Krt, con
             i2_t c[KT];
 #pragma unroll
             for (int s = 0; s < KT; ++s) {
-                c[s] = stream_load(reinterpret_cast<const i2_t *>(cols + (int64_t)s * n + i0));
-                v[s] = stream_load(reinterpret_cast<const d2_t *>(vals + (int64_t)s * n + i0));
+                c[s] = stream_load<NT>(reinterpret_cast<const i2_t *>(cols + (int64_t)s * n + i0));
+                v[s] = stream_load<NT>(reinterpret_cast<const d2_t *>(vals + (int64_t)s * n + i0));
             }
             double g0[KT], g1[KT];
 #pragma unroll
             for (int s = 0; s < KT; ++s) {
-                g0[s] = x[c[s].x >= 0 ? (int64_t)c[s].x : i0];
-                g1[s] = x[c[s].y >= 0 ? (int64_t)c[s].y : i0];
+                if constexpr (NOGATHER) {  // ablation only: wrong results
+                    g0[s] = xi.x + (double)c[s].x;
+                    g1[s] = xi.y + (double)c[s].y;
+                } else {
+                    g0[s] = x[c[s].x >= 0 ? (int64_t)c[s].x : i0];
+                    g1[s] = x[c[s].y >= 0 ? (int64_t)c[s].y : i0];
+                }
             }
 #pragma unroll
             for (int s = 0; s < KT; ++s) {
@@ -76,8 +98,8 @@ __global__ __launch_bounds__(CGH_BLOCK) void spmv_ell_r2(int64_t n, int Krt, con
         } else {
 #pragma unroll 4
             for (int s = 0; s < K; ++s) {
-                const i2_t    c = stream_load(reinterpret_cast<const i2_t *>(cols + (int64_t)s * n + i0));
-                const d2_t    v = stream_load(reinterpret_cast<const d2_t *>(vals + (int64_t)s * n + i0));
+                const i2_t    c = stream_load<NT>(reinterpret_cast<const i2_t *>(cols + (int64_t)s * n + i0));
+                const d2_t    v = stream_load<NT>(reinterpret_cast<const d2_t *>(vals + (int64_t)s * n + i0));
                 const double  g0 = x[c.x >= 0 ? (int64_t)c.x : i0];
                 const double  g1 = x[c.y >= 0 ? (int64_t)c.y : i0];
                 const double  t0 = madd_rn(a0, v.x, g0);
@@ -86,7 +108,14 @@ __global__ __launch_bounds__(CGH_BLOCK) void spmv_ell_r2(int64_t n, int Krt, con
                 a1 = c.y >= 0 ? t1 : a1;
             }
         }
-        *reinterpret_cast<double2 *>(y + i0) = make_double2(a0, a1);
+        if constexpr (NTSTORE) {
+            d2_t o;
+            o.x = a0;
+            o.y = a1;
+            __builtin_nontemporal_store(o, reinterpret_cast<d2_t *>(y + i0));
+        } else {
+            *reinterpret_cast<double2 *>(y + i0) = make_double2(a0, a1);
+        }
         if constexpr (DOT) local += xi.x * a0 + xi.y * a1;
     }
     if constexpr (DOT) {
@@ -127,14 +156,14 @@ __global__ __launch_bounds__(CGH_BLOCK) void spmv_ell_r1(int64_t n, int K, const
 
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
-template <bool DOT>
+template <bool DOT, int VAR>
 void launch_r2(int K, int grid, hipStream_t s, int64_t n, const double *diag, const double *vals, const int *cols,
                const double *x, double *y, double *partials, const int *done)
 {
 #define CGH_ELL_CASE(KK)                                                                                       \
     case KK:                                                                                                   \
-        hipLaunchKernelGGL((spmv_ell_r2<KK, DOT>), dim3(grid), dim3(CGH_BLOCK), 0, s, n, K, diag, vals, cols, x, y, \
-                           partials, done);                                                                    \
+        hipLaunchKernelGGL((spmv_ell_r2<KK, DOT, VAR>), dim3(grid), dim3(CGH_BLOCK), 0, s, n, K, diag, vals, cols, x, y, \
+                           partials, done, g_cgh.sweep_reverse);                                                                    \
         break;
     switch (K) {
         CGH_ELL_CASE(1)
@@ -148,8 +177,8 @@ void launch_r2(int K, int grid, hipStream_t s, int64_t n, const double *diag, co
         CGH_ELL_CASE(13)
         CGH_ELL_CASE(26)
     default:
-        hipLaunchKernelGGL((spmv_ell_r2<0, DOT>), dim3(grid), dim3(CGH_BLOCK), 0, s, n, K, diag, vals, cols, x, y,
-                           partials, done);
+        hipLaunchKernelGGL((spmv_ell_r2<0, DOT, VAR>), dim3(grid), dim3(CGH_BLOCK), 0, s, n, K, diag, vals, cols, x, y,
+                           partials, done, g_cgh.sweep_reverse);
     }
 #undef CGH_ELL_CASE
 }
@@ -179,10 +208,23 @@ int cgh_launch_spmv_ell(const cgh_matrix *m, const double *x, double *y, double 
     if (grid_out) *grid_out = grid;
     if (m->n == 0) return CGH_OK;
     if (ell_vector_path(m, x, y)) {
-        if (dot_partials)
-            launch_r2<true>(m->K, grid, s, m->n, m->diag, m->vals, m->cols, x, y, dot_partials, done);
-        else
-            launch_r2<false>(m->K, grid, s, m->n, m->diag, m->vals, m->cols, x, y, nullptr, done);
+        static const int var = getenv("CGH_ELL_VARIANT") ? atoi(getenv("CGH_ELL_VARIANT")) & 15 : VAR_DEFAULT;
+#define CGH_ELL_VAR(V)                                                                                         \
+    case V:                                                                                                    \
+        if (dot_partials)                                                                                      \
+            launch_r2<true, V>(m->K, grid, s, m->n, m->diag, m->vals, m->cols, x, y, dot_partials, done);      \
+        else                                                                                                   \
+            launch_r2<false, V>(m->K, grid, s, m->n, m->diag, m->vals, m->cols, x, y, nullptr, done);          \
+        break;
+        switch (var) {
+            CGH_ELL_VAR(0)
+            CGH_ELL_VAR(1)
+            CGH_ELL_VAR(2)
+            CGH_ELL_VAR(3)
+            CGH_ELL_VAR(7)
+            CGH_ELL_VAR(11)
+        }
+#undef CGH_ELL_VAR
     } else {
         if (dot_partials)
             hipLaunchKernelGGL((spmv_ell_r1<true>), dim3(grid), dim3(CGH_BLOCK), 0, s, m->n, m->K, m->diag, m->vals,

@@ -127,6 +127,18 @@ typedef struct cgh_cg_report {
 int cgh_cg_solve(const cgh_matrix *m, const double *d_b, double *d_x,
                  const cgh_cg_opts *opts, cgh_cg_report *report, double *h_history);
 
+/* Resumable form of the same loop (what cgh_cg_solve is built from): the workspace lives in the
+ * solver, iterations are queued asynchronously in batches, the host polls when it chooses. */
+typedef struct cgh_solver cgh_solver;
+cgh_solver   *cgh_solver_create(const cgh_matrix *m, int iteration_capacity);
+void          cgh_solver_free(cgh_solver *s);
+int           cgh_solver_start(cgh_solver *s, const double *d_b, double *d_x, double tol, int strict);
+int           cgh_solver_iterate(cgh_solver *s, int count, int time_kernels);
+int           cgh_solver_poll(cgh_solver *s, int *done_iter, int *queued);
+int           cgh_solver_history(cgh_solver *s, int first, int count, double *h_out);
+int           cgh_solver_spmv_ms(cgh_solver *s, double *ms_avg);
+const double *cgh_solver_residual(const cgh_solver *s);   /* device pointer to r */
+
 /* ---- timing helpers (benchmarks) ---------------------------------------- */
 /* Launch `reps` back-to-back SpMVs and return the average kernel time in ms (HIP events on the launch stream). */
 int cgh_time_spmv(const cgh_matrix *m, const double *d_x, double *d_y, int reps, double *ms_avg);
