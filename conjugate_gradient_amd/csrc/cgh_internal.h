@@ -91,5 +91,6 @@ int cgh_launch_spmv(const cgh_matrix *m, const double *x, double *y, double *dot
                     const int *done_flag, hipStream_t s);
 int cgh_spmv_grid(const cgh_matrix *m);
 
-// blas1.hip
-struct cgh_cg_ws;  // solver workspace
+// convert.hip
+cgh_matrix *cgh_matrix_from_entries_device(int64_t n, int64_t U, const double *d_diag, const double *d_upper,
+                                           const int *d_rows, const int *d_cols, int layout);

@@ -168,6 +168,44 @@ def golden_for(sysd, tag, max_iter=1000, tol=1e-6, probe_seed=1234):
         traj.shape[0] - 1, os.path.basename(path)))
 
 
+def capture_stdout(fn):
+    """run fn() with C stdout redirected into a file; return the text"""
+    import tempfile
+    libc.fflush(None)
+    saved = os.dup(1)
+    with tempfile.TemporaryFile() as tf:
+        os.dup2(tf.fileno(), 1)
+        try:
+            fn()
+            libc.fflush(None)
+        finally:
+            os.dup2(saved, 1)
+            os.close(saved)
+        tf.seek(0)
+        return tf.read().decode()
+
+
+def golden_stdout(sysd, tag, max_iter=1000, tol=1e-6):
+    """the text the reference's solvers print (banner, r[0..4], per-iteration residuals, final line)"""
+    n, U = sysd["n"], sysd["U"]
+    diag, upper, rows, cols, b = (np.ascontiguousarray(sysd[k]) for k in ("diag", "upper", "rows", "cols", "source"))
+    g = np.load(os.path.join(foamio.GOLDEN, "golden_%s.npz" % tag))
+    Kf = int(g["K_full"])
+    ev = np.ascontiguousarray(g["ell_full_vals"]); ec = np.ascontiguousarray(g["ell_full_cols"])
+    rp = np.ascontiguousarray(g["row_ptr"])
+    x = np.zeros(n)
+    texts = {
+        "ell_full": capture_stdout(lambda: ref.conjugate_gradient_ell_full_colmajor(n, D(diag), U, D(ev), I(ec), Kf, D(b), D(x), max_iter, tol)),
+        "coo": capture_stdout(lambda: ref.conjugate_gradient_coo(n, D(diag), U, D(upper), I(rows), I(cols), D(b), D(x), max_iter, tol)),
+        "csr": capture_stdout(lambda: ref.conjugate_gradient_csr(n, D(diag), U, D(upper), I(rp), I(cols), D(b), D(x), max_iter, tol)),
+        "coo_to_csr": capture_stdout(lambda: ref.coo_to_csr(n, U, D(upper), I(rows), I(cols), I(rp.copy()))),
+    }
+    for k, t in texts.items():
+        with open(os.path.join(foamio.GOLDEN, "stdout_%s_%s.txt" % (tag, k)), "w") as f:
+            f.write(t)
+        print("stdout %s/%s: %d lines" % (tag, k, t.count("\n")))
+
+
 def main():
     for name in ("2000", "8000", "32k"):
         golden_for(foamio.foam(name), "cylinder_" + name)
@@ -175,6 +213,8 @@ def main():
     golden_for(foamio.poisson_coo(16, 16, 16, 0x5EED0001, 7), "poisson7_16", max_iter=400, tol=1e-6)
     golden_for(foamio.poisson_coo(32, 24, 20, 0x5EED0001, 7), "poisson7_32x24x20", max_iter=400, tol=1e-6)
     golden_for(foamio.poisson_coo(12, 10, 8, 0x5EED0001, 27), "poisson27_12x10x8", max_iter=400, tol=1e-6)
+    golden_stdout(foamio.foam("2000"), "cylinder_2000")
+    golden_stdout(foamio.poisson_coo(12, 10, 8, 0x5EED0001, 27), "poisson27_12x10x8", max_iter=400)
 
 
 if __name__ == "__main__":
