@@ -106,6 +106,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="p7_256", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dist", action="store_true", help="use the multi-rank code path even with one rank (testing)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -120,7 +121,7 @@ def main():
     nx, ny, nz, points = WORKLOADS[args.workload]
     cga.init(local_rank)
 
-    if world > 1:
+    if world > 1 or args.dist:
         import bench_dist
         return bench_dist.run(args, rank, world, local_rank, (nx, ny, nz, points), SEED)
 

@@ -82,6 +82,43 @@ def lib():
     L.cgh_solver_spmv_ms.argtypes = [vp, dp]
     L.cgh_solver_residual.argtypes = [vp]
     L.cgh_solver_residual.restype = vp
+    i64p = C.POINTER(C.c_int64)
+    L.cgh_partition_from_coo_host.argtypes = [i64, i64, dp, dp, ip, ip, C.c_int, C.c_int, i64p]
+    L.cgh_partition_from_coo_host.restype = vp
+    L.cgh_partition_free.argtypes = [vp]
+    L.cgh_partition_free.restype = None
+    for f in ("cgh_partition_rows", "cgh_partition_first_row", "cgh_partition_halo"):
+        getattr(L, f).argtypes = [vp]
+        getattr(L, f).restype = i64
+    for f in ("cgh_partition_width", "cgh_partition_neighbours"):
+        getattr(L, f).argtypes = [vp]
+    L.cgh_partition_interior.argtypes = [vp, i64p, i64p]
+    L.cgh_partition_interior.restype = None
+    L.cgh_partition_neighbour.argtypes = [vp, C.c_int, ip, i64p, i64p, i64p]
+    L.cgh_partition_copy_send_list.argtypes = [vp, C.c_int, ip]
+    L.cgh_partition_copy_local.argtypes = [vp, dp, dp, ip, i64p]
+    L.cgh_comm_unique_id.argtypes = [C.c_char_p]
+    L.cgh_comm_init.argtypes = [C.c_int, C.c_int, C.c_char_p]
+    L.cgh_comm_destroy.restype = None
+    L.cgh_dist_from_partition.argtypes = [vp]
+    L.cgh_dist_from_partition.restype = vp
+    L.cgh_dist_poisson.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_int, C.c_int, vp]
+    L.cgh_dist_poisson.restype = vp
+    L.cgh_dist_free.argtypes = [vp]
+    L.cgh_dist_free.restype = None
+    for f in ("cgh_dist_rows", "cgh_dist_nnz_offdiag", "cgh_dist_halo"):
+        getattr(L, f).argtypes = [vp]
+        getattr(L, f).restype = i64
+    L.cgh_dist_width.argtypes = [vp]
+    L.cgh_dist_download_local.argtypes = [vp, dp, dp, ip]
+    L.cgh_dist_start.argtypes = [vp, vp, vp, C.c_double, C.c_int]
+    L.cgh_dist_iterate.argtypes = [vp, C.c_int, C.c_int]
+    L.cgh_dist_poll.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.cgh_dist_history.argtypes = [vp, C.c_int, C.c_int, dp]
+    L.cgh_dist_spmv_ms.argtypes = [vp, dp]
+    vpp = C.POINTER(vp)
+    L.cgh_dist_group_start.argtypes = [vpp, C.c_int, vpp, vpp, C.c_double, C.c_int]
+    L.cgh_dist_group_iterate.argtypes = [vpp, C.c_int, C.c_int]
     L.cgh_time_spmv.argtypes = [vp, vp, vp, C.c_int, dp]
     L.cgh_time_copy.argtypes = [vp, vp, C.c_size_t, C.c_int, dp]
     _lib = L
@@ -255,3 +292,134 @@ class Solver:
             self.free()
         except Exception:
             pass
+
+
+class Partition:
+    """One rank's share of a row-block partitioned matrix (host-side plan; needs no GPU)."""
+
+    def __init__(self, n, diag, upper, rows, cols, nranks, rank, row_starts=None):
+        rs = None
+        if row_starts is not None:
+            self._rs = np.ascontiguousarray(row_starts, dtype=np.int64)
+            rs = self._rs.ctypes.data_as(C.POINTER(C.c_int64))
+        self.h = lib().cgh_partition_from_coo_host(n, rows.size, _D(diag), _D(upper), _I(rows), _I(cols), nranks, rank, rs)
+        if not self.h:
+            raise RuntimeError("cgh_partition_from_coo_host failed (malformed input)")
+        L = lib()
+        self.nranks, self.rank = nranks, rank
+        self.n_loc = L.cgh_partition_rows(self.h)
+        self.lo = L.cgh_partition_first_row(self.h)
+        self.n_halo = L.cgh_partition_halo(self.h)
+        self.K = L.cgh_partition_width(self.h)
+        a, b = C.c_int64(), C.c_int64()
+        L.cgh_partition_interior(self.h, C.byref(a), C.byref(b))
+        self.interior = (a.value, b.value)
+        self.diag = np.empty(self.n_loc)
+        self.vals = np.empty(self.n_loc * self.K)
+        self.cols = np.empty(self.n_loc * self.K, dtype=np.int32)
+        self.halo_global = np.empty(self.n_halo, dtype=np.int64)
+        check(L.cgh_partition_copy_local(self.h, _D(self.diag), _D(self.vals), _I(self.cols),
+                                         self.halo_global.ctypes.data_as(C.POINTER(C.c_int64))), "partition_copy_local")
+        self.neighbours = []
+        for k in range(L.cgh_partition_neighbours(self.h)):
+            r, sc, ro, rc = C.c_int(), C.c_int64(), C.c_int64(), C.c_int64()
+            check(L.cgh_partition_neighbour(self.h, k, C.byref(r), C.byref(sc), C.byref(ro), C.byref(rc)), "partition_neighbour")
+            send = np.empty(sc.value, dtype=np.int32)
+            check(L.cgh_partition_copy_send_list(self.h, k, _I(send)), "partition_send_list")
+            self.neighbours.append(dict(rank=r.value, send=send, recv_off=ro.value, recv_cnt=rc.value))
+
+    def free(self):
+        if self.h:
+            lib().cgh_partition_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class DistRank:
+    """Device side of one rank (cgh_dist_*)."""
+
+    def __init__(self, handle):
+        if not handle:
+            raise RuntimeError("dist construction failed: " + lib().cgh_last_error().decode())
+        self.h = handle
+
+    @classmethod
+    def from_partition(cls, part):
+        return cls(lib().cgh_dist_from_partition(part.h))
+
+    @classmethod
+    def poisson(cls, nx, ny, nz, points, seed, nranks, rank, b=None):
+        return cls(lib().cgh_dist_poisson(nx, ny, nz, points, seed, nranks, rank, b.ptr if b is not None else None))
+
+    n_loc = property(lambda self: lib().cgh_dist_rows(self.h))
+    nnz_offdiag = property(lambda self: lib().cgh_dist_nnz_offdiag(self.h))
+    n_halo = property(lambda self: lib().cgh_dist_halo(self.h))
+    K = property(lambda self: lib().cgh_dist_width(self.h))
+
+    def download_local(self):
+        d = np.empty(self.n_loc); ev = np.empty(self.n_loc * self.K); ec = np.empty(self.n_loc * self.K, dtype=np.int32)
+        check(lib().cgh_dist_download_local(self.h, _D(d), _D(ev), _I(ec)), "dist_download_local")
+        return d, ev, ec
+
+    def start(self, b, x, tol, capacity):
+        self._keep = (b, x)
+        check(lib().cgh_dist_start(self.h, b.ptr, x.ptr, tol, capacity), "cgh_dist_start")
+
+    def iterate(self, count, time_kernels=0):
+        check(lib().cgh_dist_iterate(self.h, count, time_kernels), "cgh_dist_iterate")
+
+    def poll(self):
+        d, q = C.c_int(), C.c_int()
+        check(lib().cgh_dist_poll(self.h, C.byref(d), C.byref(q)), "cgh_dist_poll")
+        return d.value, q.value
+
+    def history(self, first, count):
+        out = np.empty((count, 4))
+        check(lib().cgh_dist_history(self.h, first, count, _D(out)), "cgh_dist_history")
+        return out
+
+    def spmv_ms(self):
+        v = C.c_double()
+        check(lib().cgh_dist_spmv_ms(self.h, C.byref(v)), "cgh_dist_spmv_ms")
+        return v.value
+
+    def free(self):
+        if self.h:
+            lib().cgh_dist_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def group_start(ranks, bs, xs, tol, capacity):
+    G = len(ranks)
+    arr = (C.c_void_p * G)(*[r.h for r in ranks])
+    ba = (C.c_void_p * G)(*[b.ptr for b in bs])
+    xa = (C.c_void_p * G)(*[x.ptr for x in xs])
+    check(lib().cgh_dist_group_start(arr, G, ba, xa, tol, capacity), "cgh_dist_group_start")
+
+
+def group_iterate(ranks, count):
+    G = len(ranks)
+    arr = (C.c_void_p * G)(*[r.h for r in ranks])
+    check(lib().cgh_dist_group_iterate(arr, G, count), "cgh_dist_group_iterate")
+
+
+def comm_unique_id():
+    buf = C.create_string_buffer(256)
+    check(lib().cgh_comm_unique_id(buf), "cgh_comm_unique_id")
+    return buf.raw
+
+
+def comm_init(nranks, rank, id_bytes):
+    assert len(id_bytes) == 256
+    check(lib().cgh_comm_init(nranks, rank, id_bytes), "cgh_comm_init")

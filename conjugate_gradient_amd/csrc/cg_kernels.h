@@ -1,0 +1,289 @@
+// cg_kernels.h -- device kernels of the CG iteration (shared by cg.hip and dist.hip; see cg.hip for the design).
+#pragma once
+#include <cmath>
+
+#include "cgh_internal.h"
+#include "device_utils.h"
+
+namespace {
+
+constexpr int HIST = 4;  // doubles per history entry: res, rr, alpha, beta
+
+typedef double d2_t __attribute__((ext_vector_type(2)));
+
+// Streaming accesses: every vector here is far larger than L2 and touched once per kernel, so loads and
+// stores are non-temporal (measured +15 % on the SpMV's y store, profiles/).  VV bit0 = nt loads, bit1 = nt stores.
+template <int VV>
+__device__ __forceinline__ double2 ld2(const double *p, int64_t k)
+{
+    if constexpr (VV & 1) {
+        const d2_t v = __builtin_nontemporal_load(reinterpret_cast<const d2_t *>(p) + k);
+        return make_double2(v.x, v.y);
+    } else {
+        return reinterpret_cast<const double2 *>(p)[k];
+    }
+}
+template <int VV>
+__device__ __forceinline__ void st2(double *p, int64_t k, double a, double b)
+{
+    if constexpr (VV & 2) {
+        d2_t v;
+        v.x = a;
+        v.y = b;
+        __builtin_nontemporal_store(v, reinterpret_cast<d2_t *>(p) + k);
+    } else {
+        reinterpret_cast<double2 *>(p)[k] = make_double2(a, b);
+    }
+}
+
+// ---------------------------------------------------------------- tree-mode kernels
+
+// r = b - Ap0 (Ap0 = A*0 computed by the SpMV, as the reference does), p = r; partials of r.r, |r|_1
+__global__ __launch_bounds__(CGH_BLOCK) void cg_init_rp(int64_t n, const double *__restrict__ b, const double *__restrict__ Ap0,
+                                                       double *__restrict__ r, double *__restrict__ p,
+                                                       double *__restrict__ partials)
+{
+    __shared__ double lds[4];
+    double            rr = 0.0, l1 = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * CGH_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * CGH_BLOCK) {
+        const double v = b[i] - Ap0[i];
+        r[i] = v;
+        p[i] = v;
+        rr += v * v;
+        l1 += fabs(v);
+    }
+    const double trr = block_sum_256(rr, lds);
+    const double tl1 = block_sum_256(l1, lds);
+    if (threadIdx.x == 0) {
+        partials[2 * blockIdx.x] = trr;
+        partials[2 * blockIdx.x + 1] = tl1;
+    }
+}
+
+__global__ __launch_bounds__(CGH_BLOCK) void cg_finish_init(const double *__restrict__ partials, int count, double *hist)
+{
+    __shared__ double lds[4];
+    const double      rr = block_sum_partials(partials, count, 2, lds);
+    const double      l1 = block_sum_partials(partials + 1, count, 2, lds);
+    if (threadIdx.x == 0) {
+        hist[0] = l1 / 2.0;
+        hist[1] = rr;
+        hist[2] = NAN;
+        hist[3] = NAN;
+    }
+}
+
+// K2.  VEC2: n even and 16-B aligned vectors.
+// MODE 0: alpha from this GPU's p.Ap partials; 1: alpha already in the history (strict sums); 2: p.Ap reduced
+// over all ranks waits in gs[0] (multi-GPU).
+template <int MODE, int VV>
+__global__ __launch_bounds__(CGH_BLOCK) void cg_update_xr(int64_t n, double *__restrict__ x, const double *__restrict__ p,
+                                                         double *__restrict__ r, const double *__restrict__ Ap,
+                                                         const double *__restrict__ pAp_partials, int pAp_count,
+                                                         double *__restrict__ out_partials, double *hist, int iter,
+                                                         const int *__restrict__ done, int rev,
+                                                         const double *__restrict__ gs)
+{
+    constexpr bool STRICT = MODE == 1;
+    __shared__ double lds[4];
+    if (*done != 0) return;
+    double alpha;
+    if constexpr (MODE == 1) {
+        alpha = hist[(size_t)iter * HIST + 2];
+    } else if constexpr (MODE == 2) {
+        alpha = hist[(size_t)(iter - 1) * HIST + 1] / gs[0];
+        if (blockIdx.x == 0 && threadIdx.x == 0) hist[(size_t)iter * HIST + 2] = alpha;
+    } else {
+        const double pAp = block_sum_partials(pAp_partials, pAp_count, 1, lds);
+        alpha = hist[(size_t)(iter - 1) * HIST + 1] / pAp;
+        if (blockIdx.x == 0 && threadIdx.x == 0) hist[(size_t)iter * HIST + 2] = alpha;
+    }
+    const double nalpha = -alpha;
+    double       rr = 0.0, l1 = 0.0;
+    const int64_t pairs = n >> 1;
+    const int64_t chunks = (pairs + CGH_BLOCK - 1) / CGH_BLOCK;
+    for (int64_t cc = blockIdx.x; cc < chunks; cc += gridDim.x) {
+        const int64_t k = (rev ? chunks - 1 - cc : cc) * CGH_BLOCK + threadIdx.x;
+        if (k >= pairs) continue;
+        const double2 xv = ld2<VV>(x, k);
+        const double2 pv = ld2<VV>(p, k);
+        const double2 rv = ld2<VV>(r, k);
+        const double2 av = ld2<VV>(Ap, k);
+        // reference vec_axpy: out = a + alpha*b (vec.c:88-94), called with alpha and -alpha (cg.c:467,469)
+        const double2 xn = make_double2(madd_rn(xv.x, alpha, pv.x), madd_rn(xv.y, alpha, pv.y));
+        const double2 rn = make_double2(madd_rn(rv.x, nalpha, av.x), madd_rn(rv.y, nalpha, av.y));
+        st2<VV>(x, k, xn.x, xn.y);
+        st2<VV>(r, k, rn.x, rn.y);
+        if constexpr (!STRICT) {
+            rr += rn.x * rn.x + rn.y * rn.y;
+            l1 += fabs(rn.x) + fabs(rn.y);
+        }
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+        const int64_t i = n - 1;
+        const double  xn = madd_rn(x[i], alpha, p[i]);
+        const double  rn = madd_rn(r[i], nalpha, Ap[i]);
+        x[i] = xn;
+        r[i] = rn;
+        if constexpr (!STRICT) {
+            rr += rn * rn;
+            l1 += fabs(rn);
+        }
+    }
+    if constexpr (!STRICT) {
+        const double trr = block_sum_256(rr, lds);
+        const double tl1 = block_sum_256(l1, lds);
+        if (threadIdx.x == 0) {
+            out_partials[2 * blockIdx.x] = trr;
+            out_partials[2 * blockIdx.x + 1] = tl1;
+        }
+    }
+}
+
+// K3.
+template <int MODE, int VV>
+__global__ __launch_bounds__(CGH_BLOCK) void cg_update_p(int64_t n, const double *__restrict__ r, double *__restrict__ p,
+                                                        const double *__restrict__ partials, int count, double *hist,
+                                                        int iter, double tol, int *done, int rev,
+                                                        const double *__restrict__ gs)
+{
+    constexpr bool STRICT = MODE == 1;
+    __shared__ double lds[4];
+    if (*done != 0) return;
+    double beta;
+    bool   conv;
+    if constexpr (MODE == 1) {
+        beta = hist[(size_t)iter * HIST + 3];
+        conv = hist[(size_t)iter * HIST + 0] < tol;
+    } else {
+        double rr, l1;
+        if constexpr (MODE == 2) {
+            rr = gs[1];
+            l1 = gs[2];
+        } else {
+            rr = block_sum_partials(partials, count, 2, lds);
+            l1 = block_sum_partials(partials + 1, count, 2, lds);
+        }
+        const double res = l1 / 2.0;  // norm_factor = 2.0, cg.c:427,475
+        conv = res < tol;
+        beta = rr / hist[(size_t)(iter - 1) * HIST + 1];
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            hist[(size_t)iter * HIST + 0] = res;
+            hist[(size_t)iter * HIST + 1] = rr;
+            hist[(size_t)iter * HIST + 3] = conv ? NAN : beta;
+        }
+    }
+    if (conv) {
+        // the reference returns before touching p (cg.c:475-485); later iterations see the flag and do nothing.
+        // Every workgroup reaches the same verdict from the same partials; workgroup 0 publishes it, and no
+        // workgroup of THIS launch reads it back.
+        if (STRICT == false && blockIdx.x == 0 && threadIdx.x == 0) *done = iter;
+        return;
+    }
+    const int64_t pairs = n >> 1;
+    const int64_t chunks = (pairs + CGH_BLOCK - 1) / CGH_BLOCK;
+    for (int64_t cc = blockIdx.x; cc < chunks; cc += gridDim.x) {
+        const int64_t k = (rev ? chunks - 1 - cc : cc) * CGH_BLOCK + threadIdx.x;
+        if (k >= pairs) continue;
+        const double2 rv = ld2<VV>(r, k);
+        const double2 pv = ld2<VV>(p, k);
+        st2<VV>(p, k, madd_rn(rv.x, beta, pv.x), madd_rn(rv.y, beta, pv.y));
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) p[n - 1] = madd_rn(r[n - 1], beta, p[n - 1]);
+}
+
+// ---------------------------------------------------------------- strict (sequential-order) sums
+//
+// One workgroup.  All 256 threads stage rounded products a[i]*b[i] (and |c[i]|) of a 2048-element
+// chunk into LDS; then ONE lane adds them left to right, exactly as reference vec_dot / vec_l1norm
+// do (vec.c:67-85).  mode 0: out = {dot}; mode 1 (CG step A): pAp -> alpha = rr_prev/pAp;
+// mode 2 (CG step B): rr, l1 -> res, beta, done flag; mode 3 (init): rr, l1 -> hist[0].
+constexpr int SEQ_CHUNK = 2048;
+
+__global__ __launch_bounds__(CGH_BLOCK) void seq_sums(int64_t n, const double *__restrict__ a, const double *__restrict__ b,
+                                                     const double *__restrict__ c, int mode, double *hist, int iter,
+                                                     double tol, int *done, double *out)
+{
+    __shared__ double prod[SEQ_CHUNK];
+    __shared__ double absv[SEQ_CHUNK];
+    if (done != nullptr && mode != 3 && mode != 0 && *done != 0) return;
+    double s_dot = 0.0, s_l1 = 0.0;
+    for (int64_t base = 0; base < n; base += SEQ_CHUNK) {
+        const int cnt = (int)((n - base) < SEQ_CHUNK ? (n - base) : SEQ_CHUNK);
+        for (int j = threadIdx.x; j < cnt; j += CGH_BLOCK) {
+            if (a != nullptr) prod[j] = mul_rn(a[base + j], b[base + j]);
+            if (c != nullptr) absv[j] = fabs(c[base + j]);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            if (a != nullptr)
+                for (int j = 0; j < cnt; ++j) s_dot = add_rn(s_dot, prod[j]);
+        }
+        if (threadIdx.x == 64) {  // a second wave runs the second chain concurrently
+            if (c != nullptr)
+                for (int j = 0; j < cnt; ++j) s_l1 = add_rn(s_l1, absv[j]);
+        }
+        __syncthreads();
+    }
+    // hand s_l1 (wave 1) to thread 0
+    if (threadIdx.x == 64) absv[0] = s_l1;
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    s_l1 = absv[0];
+    if (mode == 0) {
+        out[0] = s_dot;
+        out[1] = s_l1;
+    } else if (mode == 1) {
+        hist[(size_t)iter * HIST + 2] = hist[(size_t)(iter - 1) * HIST + 1] / s_dot;
+    } else if (mode == 2) {
+        const double res = s_l1 / 2.0;
+        const bool   conv = res < tol;
+        hist[(size_t)iter * HIST + 0] = res;
+        hist[(size_t)iter * HIST + 1] = s_dot;
+        hist[(size_t)iter * HIST + 3] = conv ? NAN : s_dot / hist[(size_t)(iter - 1) * HIST + 1];
+        if (conv) *done = iter;
+    } else {
+        hist[0] = s_l1 / 2.0;
+        hist[1] = s_dot;
+        hist[2] = NAN;
+        hist[3] = NAN;
+    }
+}
+
+// ---------------------------------------------------------------- stand-alone BLAS-1
+__global__ __launch_bounds__(CGH_BLOCK) void dot_l1_partials(int64_t n, const double *__restrict__ a, const double *__restrict__ b,
+                                                            const double *__restrict__ c, double *__restrict__ partials)
+{
+    __shared__ double lds[4];
+    double            d = 0.0, l = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * CGH_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * CGH_BLOCK) {
+        if (a != nullptr) d += a[i] * b[i];
+        if (c != nullptr) l += fabs(c[i]);
+    }
+    const double td = block_sum_256(d, lds);
+    const double tl = block_sum_256(l, lds);
+    if (threadIdx.x == 0) {
+        partials[2 * blockIdx.x] = td;
+        partials[2 * blockIdx.x + 1] = tl;
+    }
+}
+
+__global__ __launch_bounds__(CGH_BLOCK) void finish_pair(const double *__restrict__ partials, int count, double *out)
+{
+    __shared__ double lds[4];
+    const double      d = block_sum_partials(partials, count, 2, lds);
+    const double      l = block_sum_partials(partials + 1, count, 2, lds);
+    if (threadIdx.x == 0) {
+        out[0] = d;
+        out[1] = l;
+    }
+}
+
+__global__ __launch_bounds__(CGH_BLOCK) void axpy_kernel(int64_t n, const double *a, const double *b, double alpha, double *out)
+{
+    // out may alias a or b (reference vec_axpy is called both ways): element-wise, so no __restrict__
+    for (int64_t i = (int64_t)blockIdx.x * CGH_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * CGH_BLOCK)
+        out[i] = madd_rn(a[i], alpha, b[i]);
+}
+
+} // namespace

@@ -49,3 +49,15 @@ __device__ __forceinline__ double block_sum_partials(const double *parts, int co
     __syncthreads();
     return total;
 }
+
+// Counter-based hash -> double in [0,1): splitmix64 finaliser of (seed ^ idx*golden).  Integer-only, so the
+// host twin (tests/foamio.py hash01) gives the same bits.
+__device__ __host__ inline double cgh_hash01(uint64_t seed, uint64_t idx)
+{
+    uint64_t z = seed ^ (idx * 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z = z ^ (z >> 31);
+    return (double)(z >> 11) * (1.0 / 9007199254740992.0);
+}
+

@@ -1,0 +1,732 @@
+// dist.hip -- multi-GPU CG: one process per GPU, row-block partition, halo exchange of p and the two
+// scalar reductions over RCCL (xGMI).  New module, no reference counterpart.
+//
+// Per iteration on rank g (s = compute stream, c = communication stream):
+//     c: wait(p updated) ; pack boundary p entries (skipped when the list is one contiguous run) ;
+//        ncclGroup{ ncclSend to / ncclRecv from each neighbour, straight into the halo tail of p } ; record(halo)
+//     s: SpMV of the interior rows [a,b) (they reference no halo column)            -- overlaps the exchange
+//        wait(halo) ; SpMV of the boundary rows [0,a) and [b,n_loc)
+//        local p.Ap -> ncclAllReduce(1 double) ; x,r update (+ local r.r, |r|_1) -> ncclAllReduce(2 doubles) ;
+//        p update, convergence flag (identical on every rank: all see the same reduced scalars)
+// Scalars stay on the device; the host only queues work and polls the flag every `check_every` iterations.
+//
+// xGMI is point-to-point (a dedicated link per GPU pair), so the neighbour exchange is plain send/recv pairs,
+// not a ring; the all-reduces carry 8-16 bytes and are pure latency.
+//
+// A second driver (cgh_dist_group_*) runs G ranks inside ONE process on ONE device with the exchange and the
+// reductions done by device kernels: it exists so that every kernel, index list and buffer layout of this
+// path is exercised by the single-GPU test box; only the RCCL calls themselves are not.
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <vector>
+
+#include "cg_kernels.h"
+#include "partition.h"
+
+int cgh_launch_spmv_ell_range(const cgh_matrix *m, const double *x, double *y, double *dot_partials, int *grid_out,
+                              const int *done, hipStream_t s, int64_t rb, int64_t re);
+
+// ------------------------------------------------------------------------------------- RCCL, loaded lazily
+namespace {
+
+struct rccl_api {
+    void *handle = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    // two communicators, one per stream: halo send/recv lives on the communication stream, the scalar all-reduces
+    // on the compute stream; operations of ONE communicator are never in flight on two streams at once
+    ncclComm_t comm = nullptr;       // all-reduces (compute stream)
+    ncclComm_t comm_halo = nullptr;  // neighbour exchange (communication stream)
+    int        nranks = 0, rank = -1;
+} g_rccl;
+
+int load_rccl()
+{
+    if (g_rccl.handle) return CGH_OK;
+    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char *nm : names) {
+        g_rccl.handle = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
+        if (g_rccl.handle) break;
+    }
+    if (!g_rccl.handle) {
+        cgh_set_error("RCCL: cannot load librccl.so (%s)", dlerror());
+        return CGH_ECOMM;
+    }
+#define CGH_SYM(field, name)                                                          \
+    g_rccl.field = reinterpret_cast<decltype(g_rccl.field)>(dlsym(g_rccl.handle, name)); \
+    if (!g_rccl.field) {                                                              \
+        cgh_set_error("RCCL: symbol %s missing", name);                               \
+        return CGH_ECOMM;                                                             \
+    }
+    CGH_SYM(GetUniqueId, "ncclGetUniqueId")
+    CGH_SYM(CommInitRank, "ncclCommInitRank")
+    CGH_SYM(CommDestroy, "ncclCommDestroy")
+    CGH_SYM(AllReduce, "ncclAllReduce")
+    CGH_SYM(Send, "ncclSend")
+    CGH_SYM(Recv, "ncclRecv")
+    CGH_SYM(GroupStart, "ncclGroupStart")
+    CGH_SYM(GroupEnd, "ncclGroupEnd")
+    CGH_SYM(GetErrorString, "ncclGetErrorString")
+#undef CGH_SYM
+    return CGH_OK;
+}
+
+#define CGH_NCCL(call)                                                                              \
+    do {                                                                                            \
+        ncclResult_t r_ = (call);                                                                   \
+        if (r_ != ncclSuccess) {                                                                    \
+            cgh_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #call, g_rccl.GetErrorString(r_)); \
+            return CGH_ECOMM;                                                                       \
+        }                                                                                           \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------ small kernels
+__global__ __launch_bounds__(256) void gather_rows(int64_t count, const int *__restrict__ idx, const double *__restrict__ src,
+                                                  double *__restrict__ dst)
+{
+    for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < count; k += (int64_t)gridDim.x * 256) dst[k] = src[idx[k]];
+}
+
+// gs_local[slot..slot+W) = sum of W-interleaved partials (fixed order)
+template <int W>
+__global__ __launch_bounds__(CGH_BLOCK) void reduce_local(const double *__restrict__ partials, int count, double *__restrict__ out)
+{
+    __shared__ double lds[4];
+    for (int w = 0; w < W; ++w) {
+        const double v = block_sum_partials(partials + w, count, W, lds);
+        if (threadIdx.x == 0) out[w] = v;
+    }
+}
+
+__global__ void finish_init_dist(const double *__restrict__ gs, double *hist)
+{
+    hist[0] = gs[2] / 2.0;
+    hist[1] = gs[1];
+    hist[2] = NAN;
+    hist[3] = NAN;
+}
+
+// single-process rank group: out_g[w] = sum over ranks (rank order) of local_g[w], for every rank g
+__global__ void group_allreduce(int nranks, double *const *__restrict__ locals, double *const *__restrict__ outs, int first, int count)
+{
+    const int w = first + threadIdx.x;
+    if ((int)threadIdx.x >= count) return;
+    double s = 0.0;
+    for (int g = 0; g < nranks; ++g) s += locals[g][w];
+    for (int g = 0; g < nranks; ++g) outs[g][w] = s;
+}
+
+// z-slab share of the seeded Poisson stencil (see generate.hip for the global matrix): rows of planes [z0,z1),
+// local column ids: owned c-lo | lower plane n_loc + (c-(lo-nxny)) | upper plane n_loc + h_lo + (c-hi)
+template <int POINTS>
+__global__ __launch_bounds__(256) void poisson_ell_slab(int nx, int ny, int nz, int z0, int z1, int K, uint64_t seed,
+                                                       double *__restrict__ diag, double *__restrict__ vals,
+                                                       int *__restrict__ cols, double *__restrict__ b)
+{
+    const int64_t nxy = (int64_t)nx * ny, lo = nxy * z0, hi = nxy * z1, nl = hi - lo;
+    const int64_t h_lo = z0 > 0 ? nxy : 0;
+    for (int64_t li = (int64_t)blockIdx.x * 256 + threadIdx.x; li < nl; li += (int64_t)gridDim.x * 256) {
+        const int64_t i = lo + li;
+        const int     x = (int)(i % nx), y = (int)((i / nx) % ny), z = (int)(i / nxy);
+        int           slot = 0;
+#pragma unroll
+        for (int dz = -1; dz <= 1; ++dz)
+#pragma unroll
+            for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+                for (int dx = -1; dx <= 1; ++dx) {
+                    if (dz == 0 && dy == 0 && dx == 0) continue;
+                    if (POINTS == 7 && (dz != 0) + (dy != 0) + (dx != 0) != 1) continue;
+                    const int xx = x + dx, yy = y + dy, zz = z + dz;
+                    if (xx < 0 || xx >= nx || yy < 0 || yy >= ny || zz < 0 || zz >= nz) continue;
+                    const int64_t c = i + dx + (int64_t)nx * dy + nxy * dz;
+                    int64_t       lc;
+                    if (c >= lo && c < hi) lc = c - lo;
+                    else if (c < lo) lc = nl + (c - (lo - nxy));
+                    else lc = nl + h_lo + (c - hi);
+                    vals[(int64_t)slot * nl + li] = -1.0;
+                    cols[(int64_t)slot * nl + li] = (int)lc;
+                    ++slot;
+                }
+        for (; slot < K; ++slot) {
+            vals[(int64_t)slot * nl + li] = 0.0;
+            cols[(int64_t)slot * nl + li] = -1;
+        }
+        diag[li] = (double)(POINTS - 1) + 1e-3 * cgh_hash01(seed, (uint64_t)i);
+        if (b != nullptr) b[li] = cgh_hash01(seed + 1, (uint64_t)i) - 0.5;
+    }
+}
+
+inline int grid_for(int64_t work) { return cgh_stream_grid((work + 255) / 256, 8); }
+
+} // namespace
+
+// ------------------------------------------------------------------------------------------ per-rank state
+struct cgh_dist_nb {
+    int      rank = -1;
+    int     *d_send_idx = nullptr;   // local rows to send (device), NULL when contiguous
+    int64_t  send_cnt = 0;
+    int64_t  contig_start = -1;      // >= 0: the send list is rows [contig_start, contig_start+send_cnt)
+    double  *d_sendbuf = nullptr;    // packed boundary entries (only when not contiguous)
+    int64_t  recv_off = 0, recv_cnt = 0;
+};
+
+struct cgh_dist {
+    int        nranks = 1, rank = 0;
+    int64_t    n_loc = 0, n_halo = 0, nnz_off = 0;
+    int64_t    int_begin = 0, int_end = 0;
+    cgh_matrix mat;                   // local slot-major ELL; columns index the extended p vector
+    std::vector<cgh_dist_nb> nbs;
+    // solver state
+    double *p = nullptr;              // [n_loc + n_halo]: owned entries, then the halo
+    double *r = nullptr, *Ap = nullptr, *x = nullptr;
+    double *partA = nullptr, *partB = nullptr, *hist = nullptr;
+    double *gs_local = nullptr, *gs = nullptr;   // [0] p.Ap  [1] r.r  [2] |r|_1   (local / reduced over ranks)
+    int    *done = nullptr;
+    int     capacity = 0, queued = 0, vgrid = 0;
+    double  tol = 0.0;
+    hipEvent_t ev_p = nullptr, ev_halo = nullptr;
+    std::vector<hipEvent_t> kev;
+    // group driver only
+    double **d_locals = nullptr, **d_outs = nullptr;
+};
+
+namespace {
+
+void free_solver_state(cgh_dist *d)
+{
+    for (hipEvent_t e : d->kev) (void)hipEventDestroy(e);
+    d->kev.clear();
+    cgh_free(d->p);
+    cgh_free(d->r);
+    cgh_free(d->Ap);
+    cgh_free(d->partA);
+    cgh_free(d->partB);
+    cgh_free(d->hist);
+    cgh_free(d->gs_local);
+    cgh_free(d->gs);
+    cgh_free(d->done);
+    cgh_free(d->d_locals);
+    cgh_free(d->d_outs);
+    d->p = d->r = d->Ap = d->partA = d->partB = d->hist = d->gs_local = d->gs = nullptr;
+    d->done = nullptr;
+    d->d_locals = d->d_outs = nullptr;
+}
+
+int alloc_solver_state(cgh_dist *d, int capacity)
+{
+    free_solver_state(d);
+    const size_t nl = (size_t)d->n_loc;
+    d->capacity = capacity;
+    d->p = (double *)cgh_alloc(sizeof(double) * (nl + (size_t)d->n_halo));
+    d->r = (double *)cgh_alloc(sizeof(double) * nl);
+    d->Ap = (double *)cgh_alloc(sizeof(double) * nl);
+    d->partA = (double *)cgh_alloc(sizeof(double) * 3 * CGH_MAX_PARTIALS);
+    d->partB = (double *)cgh_alloc(sizeof(double) * 2 * CGH_MAX_PARTIALS);
+    d->hist = (double *)cgh_alloc(sizeof(double) * HIST * (size_t)(capacity + 1));
+    d->gs_local = (double *)cgh_alloc(sizeof(double) * 8);
+    d->gs = (double *)cgh_alloc(sizeof(double) * 8);
+    d->done = (int *)cgh_alloc(sizeof(int) * 4);
+    d->vgrid = cgh_stream_grid((d->n_loc + 2 * CGH_BLOCK - 1) / (2 * CGH_BLOCK), 8);
+    if (!d->p || !d->r || !d->Ap || !d->partA || !d->partB || !d->hist || !d->gs_local || !d->gs || !d->done) return CGH_ENOMEM;
+    if (!d->ev_p) {
+        CGH_HIP(hipEventCreateWithFlags(&d->ev_p, hipEventDisableTiming));
+        CGH_HIP(hipEventCreateWithFlags(&d->ev_halo, hipEventDisableTiming));
+    }
+    return CGH_OK;
+}
+
+// Ap[rows] = (A p)[rows] for the three row ranges; partials of p.Ap land in partA[off..); returns the partial count.
+int spmv_ranges(cgh_dist *d, bool interior, bool boundary, bool with_dot, int *count_io, hipStream_t s, const int *done)
+{
+    const int64_t a = d->int_begin, b = d->int_end, nl = d->n_loc;
+    int           g = 0, rc;
+    if (interior) {
+        rc = cgh_launch_spmv_ell_range(&d->mat, d->p, d->Ap, with_dot ? d->partA + *count_io : nullptr, &g, done, s, a, b);
+        if (rc) return rc;
+        *count_io += g;
+    }
+    if (boundary) {
+        rc = cgh_launch_spmv_ell_range(&d->mat, d->p, d->Ap, with_dot ? d->partA + *count_io : nullptr, &g, done, s, 0, a);
+        if (rc) return rc;
+        *count_io += g;
+        rc = cgh_launch_spmv_ell_range(&d->mat, d->p, d->Ap, with_dot ? d->partA + *count_io : nullptr, &g, done, s, b, nl);
+        if (rc) return rc;
+        *count_io += g;
+    }
+    return CGH_OK;
+}
+
+// RCCL halo exchange of d->p on the communication stream.
+int exchange_rccl(cgh_dist *d, hipStream_t c)
+{
+    if (d->nbs.empty()) return CGH_OK;
+    for (cgh_dist_nb &nb : d->nbs)
+        if (nb.contig_start < 0 && nb.send_cnt > 0)
+            hipLaunchKernelGGL(gather_rows, dim3(grid_for(nb.send_cnt)), dim3(256), 0, c, nb.send_cnt, (const int *)nb.d_send_idx,
+                               (const double *)d->p, nb.d_sendbuf);
+    CGH_HIP(hipGetLastError());
+    CGH_NCCL(g_rccl.GroupStart());
+    for (cgh_dist_nb &nb : d->nbs) {
+        if (nb.send_cnt > 0) {
+            const double *src = nb.contig_start >= 0 ? d->p + nb.contig_start : nb.d_sendbuf;
+            CGH_NCCL(g_rccl.Send(src, (size_t)nb.send_cnt, ncclDouble, nb.rank, g_rccl.comm_halo, c));
+        }
+        if (nb.recv_cnt > 0)
+            CGH_NCCL(g_rccl.Recv(d->p + d->n_loc + nb.recv_off, (size_t)nb.recv_cnt, ncclDouble, nb.rank, g_rccl.comm_halo, c));
+    }
+    CGH_NCCL(g_rccl.GroupEnd());
+    return CGH_OK;
+}
+
+int finish_neighbours(cgh_dist *d)
+{
+    for (cgh_dist_nb &nb : d->nbs)
+        if (nb.contig_start < 0 && nb.send_cnt > 0) {
+            nb.d_sendbuf = (double *)cgh_alloc(sizeof(double) * (size_t)nb.send_cnt);
+            if (!nb.d_sendbuf) return CGH_ENOMEM;
+        }
+    return CGH_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+// ------------------------------------------------------------------------------------------ communicator
+int cgh_comm_unique_id(char out[256])
+{
+    int rc = load_rccl();
+    if (rc) return rc;
+    static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+    for (int k = 0; k < 2; ++k) {
+        ncclUniqueId id;
+        CGH_NCCL(g_rccl.GetUniqueId(&id));
+        memcpy(out + 128 * k, &id, 128);
+    }
+    return CGH_OK;
+}
+
+int cgh_comm_init(int nranks, int rank, const char id_bytes[256])
+{
+    CGH_REQUIRE_READY(CGH_ENODEV);
+    int rc = load_rccl();
+    if (rc) return rc;
+    if (g_rccl.comm) cgh_comm_destroy();
+    ncclUniqueId id0, id1;
+    memcpy(&id0, id_bytes, 128);
+    memcpy(&id1, id_bytes + 128, 128);
+    CGH_HIP(hipSetDevice(g_cgh.device));
+    CGH_NCCL(g_rccl.CommInitRank(&g_rccl.comm, nranks, id0, rank));
+    CGH_NCCL(g_rccl.CommInitRank(&g_rccl.comm_halo, nranks, id1, rank));
+    g_rccl.nranks = nranks;
+    g_rccl.rank = rank;
+    return CGH_OK;
+}
+
+void cgh_comm_destroy(void)
+{
+    if (g_rccl.comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(g_rccl.comm);
+    if (g_rccl.comm_halo && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(g_rccl.comm_halo);
+    g_rccl.comm = g_rccl.comm_halo = nullptr;
+}
+
+// ------------------------------------------------------------------------------------------ construction
+cgh_dist *cgh_dist_from_partition(const cgh_partition *P)
+{
+    CGH_REQUIRE_READY(nullptr);
+    if (!P) return nullptr;
+    cgh_dist *d = new cgh_dist();
+    d->nranks = P->nranks;
+    d->rank = P->rank;
+    d->n_loc = P->n_loc;
+    d->n_halo = (int64_t)P->halo_global.size();
+    d->nnz_off = P->nnz_off;
+    d->int_begin = P->int_begin;
+    d->int_end = P->int_end;
+    cgh_matrix &m = d->mat;
+    m.n = P->n_loc;
+    m.K = P->K;
+    m.layout = CGH_LAYOUT_ELL;
+    m.nnz_off = P->nnz_off;
+    m.stored = P->n_loc * (int64_t)P->K;
+    m.diag = (double *)cgh_alloc(sizeof(double) * (size_t)(m.n ? m.n : 1));
+    m.vals = (double *)cgh_alloc(sizeof(double) * (size_t)(m.stored ? m.stored : 1));
+    m.cols = (int *)cgh_alloc(sizeof(int) * (size_t)(m.stored ? m.stored : 1));
+    bool ok = m.diag && m.vals && m.cols;
+    ok = ok && cgh_h2d(m.diag, P->diag.data(), sizeof(double) * (size_t)m.n) == CGH_OK;
+    ok = ok && cgh_h2d(m.vals, P->vals.data(), sizeof(double) * (size_t)m.stored) == CGH_OK;
+    ok = ok && cgh_h2d(m.cols, P->cols.data(), sizeof(int) * (size_t)m.stored) == CGH_OK;
+    for (const cgh_neighbour &src : P->nbs) {
+        if (!ok) break;
+        cgh_dist_nb nb;
+        nb.rank = src.rank;
+        nb.send_cnt = (int64_t)src.send_idx.size();
+        nb.recv_off = src.recv_off;
+        nb.recv_cnt = src.recv_cnt;
+        bool contig = nb.send_cnt > 0;
+        for (size_t k = 1; k < src.send_idx.size() && contig; ++k) contig = src.send_idx[k] == src.send_idx[k - 1] + 1;
+        if (contig) {
+            nb.contig_start = src.send_idx[0];
+        } else if (nb.send_cnt > 0) {
+            nb.d_send_idx = (int *)cgh_alloc(sizeof(int) * (size_t)nb.send_cnt);
+            ok = nb.d_send_idx && cgh_h2d(nb.d_send_idx, src.send_idx.data(), sizeof(int) * (size_t)nb.send_cnt) == CGH_OK;
+        }
+        d->nbs.push_back(nb);
+    }
+    ok = ok && finish_neighbours(d) == CGH_OK;
+    if (!ok) {
+        cgh_dist_free(d);
+        return nullptr;
+    }
+    return d;
+}
+
+cgh_dist *cgh_dist_poisson(int nx, int ny, int nz, int points, uint64_t seed, int nranks, int rank, double *d_b)
+{
+    CGH_REQUIRE_READY(nullptr);
+    if (nx < 1 || ny < 1 || nz < nranks || nranks < 1 || rank < 0 || rank >= nranks || (points != 7 && points != 27)) {
+        cgh_set_error("cgh_dist_poisson: bad arguments (%dx%dx%d, %d points, rank %d of %d; need nz >= ranks)", nx, ny, nz, points,
+                      rank, nranks);
+        return nullptr;
+    }
+    const int     z0 = (int)((int64_t)nz * rank / nranks), z1 = (int)((int64_t)nz * (rank + 1) / nranks);
+    const int64_t nxy = (int64_t)nx * ny, nl = nxy * (z1 - z0);
+    const int64_t h_lo = z0 > 0 ? nxy : 0, h_hi = z1 < nz ? nxy : 0;
+    if (nl + h_lo + h_hi > 0x7fffffffLL) {
+        cgh_set_error("cgh_dist_poisson: local block exceeds int32 column ids");
+        return nullptr;
+    }
+    auto      m3 = [](int v) { return v < 3 ? v : 3; };
+    const int K = points == 27 ? m3(nx) * m3(ny) * m3(nz) - 1 : (m3(nx) - 1) + (m3(ny) - 1) + (m3(nz) - 1);
+    cgh_dist *d = new cgh_dist();
+    d->nranks = nranks;
+    d->rank = rank;
+    d->n_loc = nl;
+    d->n_halo = h_lo + h_hi;
+    // rows needing no halo: everything but the first plane (if a lower neighbour exists) and the last (upper)
+    int64_t a = h_lo, b = nl - h_hi;
+    if (a > b) a = b = 0;
+    a = (a + 1) & ~(int64_t)1;
+    if (b < nl) b &= ~(int64_t)1;
+    if (a > b) a = b = 0;
+    d->int_begin = a;
+    d->int_end = b;
+    // stored off-diagonals of the slab
+    const int64_t inplane = points == 27 ? (3LL * nx - 2) * (3LL * ny - 2) - nxy : 2 * ((int64_t)(nx - 1) * ny + (int64_t)nx * (ny - 1));
+    const int64_t perz = points == 27 ? (3LL * nx - 2) * (3LL * ny - 2) : nxy;
+    int64_t       nnz = 0;
+    for (int z = z0; z < z1; ++z) nnz += inplane + perz * ((z > 0) + (z < nz - 1));
+    d->nnz_off = nnz;
+    cgh_matrix &m = d->mat;
+    m.n = nl;
+    m.K = K;
+    m.layout = CGH_LAYOUT_ELL;
+    m.nnz_off = nnz;
+    m.stored = nl * (int64_t)K;
+    m.diag = (double *)cgh_alloc(sizeof(double) * (size_t)nl);
+    m.vals = (double *)cgh_alloc(sizeof(double) * (size_t)(m.stored ? m.stored : 1));
+    m.cols = (int *)cgh_alloc(sizeof(int) * (size_t)(m.stored ? m.stored : 1));
+    if (!m.diag || !m.vals || !m.cols) {
+        cgh_dist_free(d);
+        return nullptr;
+    }
+    hipStream_t s = g_cgh.stream;
+    if (points == 7)
+        hipLaunchKernelGGL(poisson_ell_slab<7>, dim3(grid_for(nl)), dim3(256), 0, s, nx, ny, nz, z0, z1, K, seed, m.diag, m.vals, m.cols, d_b);
+    else
+        hipLaunchKernelGGL(poisson_ell_slab<27>, dim3(grid_for(nl)), dim3(256), 0, s, nx, ny, nz, z0, z1, K, seed, m.diag, m.vals, m.cols, d_b);
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
+        cgh_set_error("cgh_dist_poisson: generator kernel failed");
+        cgh_dist_free(d);
+        return nullptr;
+    }
+    if (h_lo) {
+        cgh_dist_nb nb;
+        nb.rank = rank - 1;
+        nb.send_cnt = nxy;
+        nb.contig_start = 0;
+        nb.recv_off = 0;
+        nb.recv_cnt = nxy;
+        d->nbs.push_back(nb);
+    }
+    if (h_hi) {
+        cgh_dist_nb nb;
+        nb.rank = rank + 1;
+        nb.send_cnt = nxy;
+        nb.contig_start = nl - nxy;
+        nb.recv_off = h_lo;
+        nb.recv_cnt = nxy;
+        d->nbs.push_back(nb);
+    }
+    return d;
+}
+
+void cgh_dist_free(cgh_dist *d)
+{
+    if (!d) return;
+    free_solver_state(d);
+    if (d->ev_p) (void)hipEventDestroy(d->ev_p);
+    if (d->ev_halo) (void)hipEventDestroy(d->ev_halo);
+    for (cgh_dist_nb &nb : d->nbs) {
+        cgh_free(nb.d_send_idx);
+        cgh_free(nb.d_sendbuf);
+    }
+    cgh_free(d->mat.diag);
+    cgh_free(d->mat.vals);
+    cgh_free(d->mat.cols);
+    delete d;
+}
+
+int64_t cgh_dist_rows(const cgh_dist *d) { return d ? d->n_loc : 0; }
+int64_t cgh_dist_nnz_offdiag(const cgh_dist *d) { return d ? d->nnz_off : 0; }
+
+// Debug / test access: the local ELL (slot-major, local column ids) and the neighbour table.
+int cgh_dist_download_local(const cgh_dist *d, double *diag, double *ell_vals, int *ell_cols)
+{
+    int rc = cgh_d2h(diag, d->mat.diag, sizeof(double) * (size_t)d->n_loc);
+    if (rc) return rc;
+    rc = cgh_d2h(ell_vals, d->mat.vals, sizeof(double) * (size_t)d->mat.stored);
+    if (rc) return rc;
+    return cgh_d2h(ell_cols, d->mat.cols, sizeof(int) * (size_t)d->mat.stored);
+}
+int cgh_dist_width(const cgh_dist *d) { return d->mat.K; }
+int64_t cgh_dist_halo(const cgh_dist *d) { return d->n_halo; }
+
+// ------------------------------------------------------------------------------------------ RCCL-driven loop
+int cgh_dist_start(cgh_dist *d, const double *d_b, double *d_x, double tol, int capacity)
+{
+    CGH_REQUIRE_READY(CGH_ENODEV);
+    if (!d || !d_b || !d_x || capacity < 1) return CGH_EINVAL;
+    if (!g_rccl.comm || g_rccl.nranks != d->nranks || g_rccl.rank != d->rank) {
+        cgh_set_error("cgh_dist_start: no RCCL communicator for rank %d of %d (call cgh_comm_init first)", d->rank, d->nranks);
+        return CGH_ECOMM;
+    }
+    int rc = alloc_solver_state(d, capacity);
+    if (rc) return rc;
+    hipStream_t   s = g_cgh.stream;
+    const int64_t nl = d->n_loc;
+    d->x = d_x;
+    d->tol = tol;
+    d->queued = 0;
+    CGH_HIP(hipMemsetAsync(d->done, 0, sizeof(int) * 4, s));
+    CGH_HIP(hipMemsetAsync(d_x, 0, sizeof(double) * (size_t)nl, s));
+    CGH_HIP(hipMemsetAsync(d->p, 0, sizeof(double) * (size_t)(nl + d->n_halo), s));  // x0 = 0, halo of x0 = 0
+    int cnt = 0;
+    rc = spmv_ranges(d, true, true, false, &cnt, s, nullptr);  // Ap = A*0, as the reference computes it (cg.c:441)
+    if (rc) return rc;
+    hipLaunchKernelGGL(cg_init_rp, dim3(d->vgrid), dim3(CGH_BLOCK), 0, s, nl, d_b, (const double *)d->Ap, d->r, d->p, d->partB);
+    hipLaunchKernelGGL(reduce_local<2>, dim3(1), dim3(CGH_BLOCK), 0, s, (const double *)d->partB, d->vgrid, d->gs_local + 1);
+    CGH_HIP(hipGetLastError());
+    CGH_NCCL(g_rccl.AllReduce(d->gs_local + 1, d->gs + 1, 2, ncclDouble, ncclSum, g_rccl.comm, s));
+    hipLaunchKernelGGL(finish_init_dist, dim3(1), dim3(1), 0, s, (const double *)d->gs, d->hist);
+    CGH_HIP(hipGetLastError());
+    return CGH_OK;
+}
+
+int cgh_dist_iterate(cgh_dist *d, int count, int time_kernels)
+{
+    CGH_REQUIRE_READY(CGH_ENODEV);
+    if (!d || count < 0 || d->queued + count > d->capacity) {
+        cgh_set_error("cgh_dist_iterate: count exceeds the capacity given to cgh_dist_start");
+        return CGH_EINVAL;
+    }
+    hipStream_t   s = g_cgh.stream, c = g_cgh.comm_stream;
+    const int64_t nl = d->n_loc;
+    for (int k = 0; k < count; ++k) {
+        const int iter = ++d->queued;
+        // halo exchange of p on the communication stream, behind the kernel that last wrote p
+        CGH_HIP(hipEventRecord(d->ev_p, s));
+        CGH_HIP(hipStreamWaitEvent(c, d->ev_p, 0));
+        int rc = exchange_rccl(d, c);
+        if (rc) return rc;
+        CGH_HIP(hipEventRecord(d->ev_halo, c));
+        if (time_kernels) {
+            hipEvent_t a, b;
+            CGH_HIP(hipEventCreate(&a));
+            CGH_HIP(hipEventCreate(&b));
+            d->kev.push_back(a);
+            d->kev.push_back(b);
+            CGH_HIP(hipEventRecord(a, s));
+        }
+        int cnt = 0;
+        rc = spmv_ranges(d, true, false, true, &cnt, s, d->done);   // interior rows: overlap the exchange
+        if (rc) return rc;
+        CGH_HIP(hipStreamWaitEvent(s, d->ev_halo, 0));
+        rc = spmv_ranges(d, false, true, true, &cnt, s, d->done);   // boundary rows
+        if (rc) return rc;
+        if (time_kernels) CGH_HIP(hipEventRecord(d->kev.back(), s));
+        hipLaunchKernelGGL(reduce_local<1>, dim3(1), dim3(CGH_BLOCK), 0, s, (const double *)d->partA, cnt, d->gs_local);
+        CGH_NCCL(g_rccl.AllReduce(d->gs_local, d->gs, 1, ncclDouble, ncclSum, g_rccl.comm, s));
+        hipLaunchKernelGGL((cg_update_xr<2, 3>), dim3(d->vgrid), dim3(CGH_BLOCK), 0, s, nl, d->x, (const double *)d->p, d->r,
+                           (const double *)d->Ap, (const double *)nullptr, 0, d->partB, d->hist, iter, (const int *)d->done, 0,
+                           (const double *)d->gs);
+        hipLaunchKernelGGL(reduce_local<2>, dim3(1), dim3(CGH_BLOCK), 0, s, (const double *)d->partB, d->vgrid, d->gs_local + 1);
+        CGH_NCCL(g_rccl.AllReduce(d->gs_local + 1, d->gs + 1, 2, ncclDouble, ncclSum, g_rccl.comm, s));
+        hipLaunchKernelGGL((cg_update_p<2, 3>), dim3(d->vgrid), dim3(CGH_BLOCK), 0, s, nl, (const double *)d->r, d->p,
+                           (const double *)nullptr, 0, d->hist, iter, d->tol, d->done, 0, (const double *)d->gs);
+        CGH_HIP(hipGetLastError());
+    }
+    return CGH_OK;
+}
+
+int cgh_dist_poll(cgh_dist *d, int *done_iter, int *queued)
+{
+    CGH_REQUIRE_READY(CGH_ENODEV);
+    if (!d) return CGH_EINVAL;
+    hipStream_t s = g_cgh.stream;
+    // every rank derives the flag from the same reduced scalars; the max-reduce makes agreement explicit, so that
+    // all ranks stop queueing (collectives!) at the same poll
+    if (g_rccl.comm && d->nranks > 1) CGH_NCCL(g_rccl.AllReduce(d->done, d->done + 1, 1, ncclInt32, ncclMax, g_rccl.comm, s));
+    int v[2] = {0, 0};
+    CGH_HIP(hipMemcpyAsync(v, d->done, sizeof(int) * 2, hipMemcpyDeviceToHost, s));
+    CGH_HIP(hipStreamSynchronize(s));
+    CGH_HIP(hipStreamSynchronize(g_cgh.comm_stream));
+    if (done_iter) *done_iter = (g_rccl.comm && d->nranks > 1) ? v[1] : v[0];
+    if (queued) *queued = d->queued;
+    return CGH_OK;
+}
+
+int cgh_dist_history(cgh_dist *d, int first, int count, double *h_out)
+{
+    CGH_REQUIRE_READY(CGH_ENODEV);
+    if (!d || first < 0 || count < 0 || first + count > d->capacity + 1) return CGH_EINVAL;
+    return cgh_d2h(h_out, d->hist + (size_t)first * HIST, sizeof(double) * HIST * (size_t)count);
+}
+
+int cgh_dist_spmv_ms(cgh_dist *d, double *ms_avg)
+{
+    CGH_REQUIRE_READY(CGH_ENODEV);
+    if (!d || !ms_avg) return CGH_EINVAL;
+    CGH_HIP(hipStreamSynchronize(g_cgh.stream));
+    double tot = 0.0;
+    for (size_t k = 0; k + 1 < d->kev.size(); k += 2) {
+        float t = 0.f;
+        CGH_HIP(hipEventElapsedTime(&t, d->kev[k], d->kev[k + 1]));
+        tot += t;
+    }
+    *ms_avg = d->kev.empty() ? 0.0 : tot / (double)(d->kev.size() / 2);
+    return CGH_OK;
+}
+
+// ------------------------------------------------------------------------------------------ single-process rank group
+static cgh_dist_nb *find_nb(cgh_dist *d, int rank)
+{
+    for (cgh_dist_nb &nb : d->nbs)
+        if (nb.rank == rank) return &nb;
+    return nullptr;
+}
+
+static int group_exchange(cgh_dist **R, int G, hipStream_t s)
+{
+    for (int g = 0; g < G; ++g)
+        for (cgh_dist_nb &nb : R[g]->nbs) {
+            if (nb.recv_cnt == 0) continue;
+            cgh_dist    *q = R[nb.rank];
+            cgh_dist_nb *back = find_nb(q, g);
+            if (!back || back->send_cnt != nb.recv_cnt) {
+                cgh_set_error("group exchange: rank %d expects %lld entries from rank %d, which sends %lld", g, (long long)nb.recv_cnt,
+                              nb.rank, back ? (long long)back->send_cnt : -1LL);
+                return CGH_EINVAL;
+            }
+            double *dst = R[g]->p + R[g]->n_loc + nb.recv_off;
+            if (back->contig_start >= 0)
+                CGH_HIP(hipMemcpyAsync(dst, q->p + back->contig_start, sizeof(double) * (size_t)nb.recv_cnt, hipMemcpyDeviceToDevice, s));
+            else
+                hipLaunchKernelGGL(gather_rows, dim3(grid_for(nb.recv_cnt)), dim3(256), 0, s, nb.recv_cnt, (const int *)back->d_send_idx,
+                                   (const double *)q->p, dst);
+        }
+    CGH_HIP(hipGetLastError());
+    return CGH_OK;
+}
+
+int cgh_dist_group_start(cgh_dist **R, int G, const double *const *d_b, double *const *d_x, double tol, int capacity)
+{
+    CGH_REQUIRE_READY(CGH_ENODEV);
+    if (!R || G < 1 || G > 64) return CGH_EINVAL;
+    hipStream_t s = g_cgh.stream;
+    std::vector<double *> locals((size_t)G), outs((size_t)G);
+    for (int g = 0; g < G; ++g) {
+        int rc = alloc_solver_state(R[g], capacity);
+        if (rc) return rc;
+        locals[(size_t)g] = R[g]->gs_local;
+        outs[(size_t)g] = R[g]->gs;
+    }
+    cgh_dist *d0 = R[0];
+    d0->d_locals = (double **)cgh_alloc(sizeof(double *) * (size_t)G);
+    d0->d_outs = (double **)cgh_alloc(sizeof(double *) * (size_t)G);
+    if (!d0->d_locals || !d0->d_outs) return CGH_ENOMEM;
+    int rc = cgh_h2d(d0->d_locals, locals.data(), sizeof(double *) * (size_t)G);
+    if (rc == CGH_OK) rc = cgh_h2d(d0->d_outs, outs.data(), sizeof(double *) * (size_t)G);
+    if (rc) return rc;
+    for (int g = 0; g < G; ++g) {
+        cgh_dist *d = R[g];
+        d->x = d_x[g];
+        d->tol = tol;
+        d->queued = 0;
+        CGH_HIP(hipMemsetAsync(d->done, 0, sizeof(int) * 4, s));
+        CGH_HIP(hipMemsetAsync(d->x, 0, sizeof(double) * (size_t)d->n_loc, s));
+        CGH_HIP(hipMemsetAsync(d->p, 0, sizeof(double) * (size_t)(d->n_loc + d->n_halo), s));
+        int cnt = 0;
+        rc = spmv_ranges(d, true, true, false, &cnt, s, nullptr);
+        if (rc) return rc;
+        hipLaunchKernelGGL(cg_init_rp, dim3(d->vgrid), dim3(CGH_BLOCK), 0, s, d->n_loc, d_b[g], (const double *)d->Ap, d->r, d->p, d->partB);
+        hipLaunchKernelGGL(reduce_local<2>, dim3(1), dim3(CGH_BLOCK), 0, s, (const double *)d->partB, d->vgrid, d->gs_local + 1);
+    }
+    hipLaunchKernelGGL(group_allreduce, dim3(1), dim3(64), 0, s, G, (double *const *)d0->d_locals, (double *const *)d0->d_outs, 1, 2);
+    for (int g = 0; g < G; ++g) hipLaunchKernelGGL(finish_init_dist, dim3(1), dim3(1), 0, s, (const double *)R[g]->gs, R[g]->hist);
+    CGH_HIP(hipGetLastError());
+    return CGH_OK;
+}
+
+int cgh_dist_group_iterate(cgh_dist **R, int G, int count)
+{
+    CGH_REQUIRE_READY(CGH_ENODEV);
+    if (!R || G < 1 || !R[0]->d_locals) return CGH_EINVAL;
+    hipStream_t s = g_cgh.stream;
+    cgh_dist   *d0 = R[0];
+    for (int k = 0; k < count; ++k) {
+        std::vector<int> cnt((size_t)G, 0);
+        // interior rows first (they never read the halo), then the exchange, then the boundary rows: the same order of
+        // dependencies as the two-stream RCCL loop, serialised on one stream
+        for (int g = 0; g < G; ++g) {
+            if (R[g]->queued + 1 > R[g]->capacity) return CGH_EINVAL;
+            int rc = spmv_ranges(R[g], true, false, true, &cnt[(size_t)g], s, R[g]->done);
+            if (rc) return rc;
+        }
+        int rc = group_exchange(R, G, s);
+        if (rc) return rc;
+        for (int g = 0; g < G; ++g) {
+            rc = spmv_ranges(R[g], false, true, true, &cnt[(size_t)g], s, R[g]->done);
+            if (rc) return rc;
+            hipLaunchKernelGGL(reduce_local<1>, dim3(1), dim3(CGH_BLOCK), 0, s, (const double *)R[g]->partA, cnt[(size_t)g], R[g]->gs_local);
+        }
+        hipLaunchKernelGGL(group_allreduce, dim3(1), dim3(64), 0, s, G, (double *const *)d0->d_locals, (double *const *)d0->d_outs, 0, 1);
+        for (int g = 0; g < G; ++g) {
+            cgh_dist *d = R[g];
+            const int iter = ++d->queued;
+            hipLaunchKernelGGL((cg_update_xr<2, 3>), dim3(d->vgrid), dim3(CGH_BLOCK), 0, s, d->n_loc, d->x, (const double *)d->p, d->r,
+                               (const double *)d->Ap, (const double *)nullptr, 0, d->partB, d->hist, iter, (const int *)d->done, 0,
+                               (const double *)d->gs);
+            hipLaunchKernelGGL(reduce_local<2>, dim3(1), dim3(CGH_BLOCK), 0, s, (const double *)d->partB, d->vgrid, d->gs_local + 1);
+        }
+        hipLaunchKernelGGL(group_allreduce, dim3(1), dim3(64), 0, s, G, (double *const *)d0->d_locals, (double *const *)d0->d_outs, 1, 2);
+        for (int g = 0; g < G; ++g) {
+            cgh_dist *d = R[g];
+            hipLaunchKernelGGL((cg_update_p<2, 3>), dim3(d->vgrid), dim3(CGH_BLOCK), 0, s, d->n_loc, (const double *)d->r, d->p,
+                               (const double *)nullptr, 0, d->hist, d->queued, d->tol, d->done, 0, (const double *)d->gs);
+        }
+        CGH_HIP(hipGetLastError());
+    }
+    return CGH_OK;
+}
+
+} // extern "C"

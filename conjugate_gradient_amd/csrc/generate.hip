@@ -12,15 +12,7 @@
 // upper entries), so the full ELL can be written directly, one thread per row, bit-identical to
 // that conversion (tests/test_generate.py checks it through the oracle).
 #include "cgh_internal.h"
-
-__device__ __host__ inline double cgh_hash01(uint64_t seed, uint64_t idx)
-{
-    uint64_t z = seed ^ (idx * 0x9E3779B97F4A7C15ull);
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    z = z ^ (z >> 31);
-    return (double)(z >> 11) * (1.0 / 9007199254740992.0);
-}
+#include "device_utils.h"
 
 namespace {
 

@@ -42,12 +42,13 @@ __global__ __launch_bounds__(CGH_BLOCK) void spmv_ell_r2(int64_t n, int Krt, con
                                                         const double *__restrict__ vals, const int *__restrict__ cols,
                                                         const double *__restrict__ x, double *__restrict__ y,
                                                         double *__restrict__ partials, const int *__restrict__ done,
-                                                        int rev)
+                                                        int rev, int64_t row_begin, int64_t row_end)
 {
     __shared__ double lds[4];
     if (done != nullptr && *done != 0) return;
     const int     K = KT > 0 ? KT : Krt;
-    const int64_t pairs = n >> 1;  // n is even on this path
+    const int64_t pair0 = row_begin >> 1;              // rows [row_begin,row_end): both even on this path
+    const int64_t pairs = (row_end >> 1) - pair0;
     double        local = 0.0;
 
     // Tile walk.  Workgroup-iteration j (= blockIdx + k*gridDim, gridDim a multiple of 8) runs on XCD
@@ -64,7 +65,7 @@ __global__ __launch_bounds__(CGH_BLOCK) void spmv_ell_r2(int64_t n, int Krt, con
         const int64_t t = REMAP ? ((q >> 3) << 6) + ((j & 7) << 3) + (q & 7) : j;
         const int64_t pr = t * CGH_BLOCK + threadIdx.x;
         if (pr >= pairs) continue;
-        const int64_t i0 = pr << 1;
+        const int64_t i0 = (pair0 + pr) << 1;
         const double2 d = *reinterpret_cast<const double2 *>(diag + i0);
         const double2 xi = *reinterpret_cast<const double2 *>(x + i0);
         double        a0 = add_rn(0.0, mul_rn(d.x, xi.x));
@@ -129,12 +130,13 @@ template <bool DOT>
 __global__ __launch_bounds__(CGH_BLOCK) void spmv_ell_r1(int64_t n, int K, const double *__restrict__ diag,
                                                         const double *__restrict__ vals, const int *__restrict__ cols,
                                                         const double *__restrict__ x, double *__restrict__ y,
-                                                        double *__restrict__ partials, const int *__restrict__ done)
+                                                        double *__restrict__ partials, const int *__restrict__ done,
+                                                        int64_t row_begin, int64_t row_end)
 {
     __shared__ double lds[4];
     if (done != nullptr && *done != 0) return;
     double local = 0.0;
-    for (int64_t i = (int64_t)blockIdx.x * CGH_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * CGH_BLOCK) {
+    for (int64_t i = row_begin + (int64_t)blockIdx.x * CGH_BLOCK + threadIdx.x; i < row_end; i += (int64_t)gridDim.x * CGH_BLOCK) {
         const double xi = x[i];
         double       a = add_rn(0.0, mul_rn(diag[i], xi));
 #pragma unroll 4
@@ -158,12 +160,12 @@ inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 template <bool DOT, int VAR>
 void launch_r2(int K, int grid, hipStream_t s, int64_t n, const double *diag, const double *vals, const int *cols,
-               const double *x, double *y, double *partials, const int *done)
+               const double *x, double *y, double *partials, const int *done, int64_t rb, int64_t re)
 {
 #define CGH_ELL_CASE(KK)                                                                                       \
     case KK:                                                                                                   \
         hipLaunchKernelGGL((spmv_ell_r2<KK, DOT, VAR>), dim3(grid), dim3(CGH_BLOCK), 0, s, n, K, diag, vals, cols, x, y, \
-                           partials, done, g_cgh.sweep_reverse);                                                                    \
+                           partials, done, g_cgh.sweep_reverse, rb, re);                                                                    \
         break;
     switch (K) {
         CGH_ELL_CASE(1)
@@ -178,7 +180,7 @@ void launch_r2(int K, int grid, hipStream_t s, int64_t n, const double *diag, co
         CGH_ELL_CASE(26)
     default:
         hipLaunchKernelGGL((spmv_ell_r2<0, DOT, VAR>), dim3(grid), dim3(CGH_BLOCK), 0, s, n, K, diag, vals, cols, x, y,
-                           partials, done, g_cgh.sweep_reverse);
+                           partials, done, g_cgh.sweep_reverse, rb, re);
     }
 #undef CGH_ELL_CASE
 }
@@ -192,29 +194,35 @@ static inline bool ell_vector_path(const cgh_matrix *m, const double *x, const d
            (reinterpret_cast<uintptr_t>(m->cols) & 7u) == 0;
 }
 
-int cgh_ell_grid(const cgh_matrix *m)
+static int ell_grid_rows(int64_t rows)
 {
     // tiles of 512 rows (256 threads x 2 rows); grid a multiple of 8 so tile%8 -> XCD group is stable
-    const int64_t tiles = (m->n + 2 * CGH_BLOCK - 1) / (2 * CGH_BLOCK);
+    const int64_t tiles = (rows + 2 * CGH_BLOCK - 1) / (2 * CGH_BLOCK);
     int           g = cgh_stream_grid(tiles, 8);
     if (g >= 8) g -= g % 8;
     return g;
 }
 
-int cgh_launch_spmv_ell(const cgh_matrix *m, const double *x, double *y, double *dot_partials, int *grid_out,
-                        const int *done, hipStream_t s)
+int cgh_ell_grid(const cgh_matrix *m) { return ell_grid_rows(m->n); }
+
+// y[rb:re) = (A x)[rb:re).  The slot stride is m->n; x may be longer than n (multi-GPU: halo entries follow the owned ones).
+int cgh_launch_spmv_ell_range(const cgh_matrix *m, const double *x, double *y, double *dot_partials, int *grid_out,
+                              const int *done, hipStream_t s, int64_t rb, int64_t re)
 {
-    const int grid = cgh_ell_grid(m);
-    if (grid_out) *grid_out = grid;
-    if (m->n == 0) return CGH_OK;
-    if (ell_vector_path(m, x, y)) {
-        static const int var = getenv("CGH_ELL_VARIANT") ? atoi(getenv("CGH_ELL_VARIANT")) & 15 : VAR_DEFAULT;
-#define CGH_ELL_VAR(V)                                                                                         \
-    case V:                                                                                                    \
-        if (dot_partials)                                                                                      \
-            launch_r2<true, V>(m->K, grid, s, m->n, m->diag, m->vals, m->cols, x, y, dot_partials, done);      \
-        else                                                                                                   \
-            launch_r2<false, V>(m->K, grid, s, m->n, m->diag, m->vals, m->cols, x, y, nullptr, done);          \
+    const int grid = ell_grid_rows(re - rb);
+    if (grid_out) *grid_out = re > rb ? grid : 0;
+    if (re <= rb) return CGH_OK;
+    if (ell_vector_path(m, x, y) && rb % 2 == 0 && re % 2 == 0) {
+        static const int var = [] {
+            const int v = getenv("CGH_ELL_VARIANT") ? atoi(getenv("CGH_ELL_VARIANT")) : VAR_DEFAULT;
+            return (v == 0 || v == 1 || v == 2 || v == 3 || v == 7 || v == 11) ? v : VAR_DEFAULT;
+        }();
+#define CGH_ELL_VAR(V)                                                                                                  \
+    case V:                                                                                                             \
+        if (dot_partials)                                                                                               \
+            launch_r2<true, V>(m->K, grid, s, m->n, m->diag, m->vals, m->cols, x, y, dot_partials, done, rb, re);       \
+        else                                                                                                            \
+            launch_r2<false, V>(m->K, grid, s, m->n, m->diag, m->vals, m->cols, x, y, nullptr, done, rb, re);           \
         break;
         switch (var) {
             CGH_ELL_VAR(0)
@@ -228,11 +236,21 @@ int cgh_launch_spmv_ell(const cgh_matrix *m, const double *x, double *y, double 
     } else {
         if (dot_partials)
             hipLaunchKernelGGL((spmv_ell_r1<true>), dim3(grid), dim3(CGH_BLOCK), 0, s, m->n, m->K, m->diag, m->vals,
-                               m->cols, x, y, dot_partials, done);
+                               m->cols, x, y, dot_partials, done, rb, re);
         else
             hipLaunchKernelGGL((spmv_ell_r1<false>), dim3(grid), dim3(CGH_BLOCK), 0, s, m->n, m->K, m->diag, m->vals,
-                               m->cols, x, y, nullptr, done);
+                               m->cols, x, y, (double *)nullptr, done, rb, re);
     }
     CGH_HIP(hipGetLastError());
     return CGH_OK;
+}
+
+int cgh_launch_spmv_ell(const cgh_matrix *m, const double *x, double *y, double *dot_partials, int *grid_out,
+                        const int *done, hipStream_t s)
+{
+    if (m->n == 0) {
+        if (grid_out) *grid_out = 0;
+        return CGH_OK;
+    }
+    return cgh_launch_spmv_ell_range(m, x, y, dot_partials, grid_out, done, s, 0, m->n);
 }

@@ -139,6 +139,64 @@ int           cgh_solver_history(cgh_solver *s, int first, int count, double *h_
 int           cgh_solver_spmv_ms(cgh_solver *s, double *ms_avg);
 const double *cgh_solver_residual(const cgh_solver *s);   /* device pointer to r */
 
+/* ---- multi-GPU: row-block partition + halo exchange (one process per GPU, RCCL over xGMI) ---------------
+ * No reference counterpart (the reference is serial).  Rank g owns a contiguous row block; per iteration the
+ * boundary entries of p go to the neighbouring ranks (ncclSend/ncclRecv on a communication stream, overlapped
+ * with the SpMV of the rows that need no halo) and the two scalar reductions are ncclAllReduce.
+ */
+typedef struct cgh_partition cgh_partition;   /* host-side description of one rank's share (no GPU needed) */
+typedef struct cgh_dist cgh_dist;             /* device-side distributed solver of one rank */
+
+/* Rank `rank`'s share of the n-row matrix given as a global upper-triangular COO on the host.
+ * row_starts: nranks+1 block starts, or NULL for an even split.  NULL on malformed input. */
+cgh_partition *cgh_partition_from_coo_host(int64_t n, int64_t nnz_upper, const double *diag, const double *upper,
+                                           const int *rows, const int *cols, int nranks, int rank,
+                                           const int64_t *row_starts);
+void    cgh_partition_free(cgh_partition *p);
+int64_t cgh_partition_rows(const cgh_partition *p);        /* owned rows */
+int64_t cgh_partition_first_row(const cgh_partition *p);   /* global index of the first owned row */
+int64_t cgh_partition_halo(const cgh_partition *p);        /* halo entries (distinct off-block columns) */
+int     cgh_partition_width(const cgh_partition *p);       /* local ELL width */
+int     cgh_partition_neighbours(const cgh_partition *p);
+void    cgh_partition_interior(const cgh_partition *p, int64_t *begin, int64_t *end);  /* rows needing no halo */
+int     cgh_partition_neighbour(const cgh_partition *p, int k, int *rank, int64_t *send_count, int64_t *recv_off,
+                                int64_t *recv_count);
+int     cgh_partition_copy_send_list(const cgh_partition *p, int k, int *out_local_rows);
+/* local slot-major ELL (rows x width, local column ids: owned < rows <= halo), diag, global column of each halo slot */
+int     cgh_partition_copy_local(const cgh_partition *p, double *diag, double *ell_vals, int *ell_cols,
+                                 int64_t *halo_global);
+
+/* RCCL bootstrap: rank 0 calls cgh_comm_unique_id, the 256 bytes (two ncclUniqueIds: one communicator for the
+ * halo exchange, one for the all-reduces) travel to the other ranks by any means (bench.py:
+ * torch.distributed/gloo broadcast), then every rank calls cgh_comm_init. */
+int cgh_comm_unique_id(char out_256_bytes[256]);
+int cgh_comm_init(int nranks, int rank, const char id_256_bytes[256]);
+void cgh_comm_destroy(void);
+
+/* Device side of a rank: from a host partition, or generated on the device for the z-slab partition of the
+ * seeded Poisson stencils (rank g owns planes [nz*g/G, nz*(g+1)/G)); d_b (may be NULL) gets the local rhs. */
+cgh_dist *cgh_dist_from_partition(const cgh_partition *p);
+cgh_dist *cgh_dist_poisson(int nx, int ny, int nz, int points, uint64_t seed, int nranks, int rank, double *d_b);
+void      cgh_dist_free(cgh_dist *d);
+int64_t   cgh_dist_rows(const cgh_dist *d);
+int64_t   cgh_dist_nnz_offdiag(const cgh_dist *d);
+/* The resumable CG loop on the rank's rows (same contract as cgh_solver_*; collective: every rank calls it
+ * with the same counts).  transport: RCCL communicator from cgh_comm_init. */
+int cgh_dist_start(cgh_dist *d, const double *d_b_local, double *d_x_local, double tol, int iteration_capacity);
+int cgh_dist_iterate(cgh_dist *d, int count, int time_kernels);
+int cgh_dist_poll(cgh_dist *d, int *done_iter, int *queued);
+int cgh_dist_history(cgh_dist *d, int first, int count, double *h_out);
+int cgh_dist_spmv_ms(cgh_dist *d, double *ms_avg);
+/* Test harness: the same per-rank code paths with `nranks` ranks living in ONE process on ONE device, the halo
+ * exchange and the reductions done by device copies instead of RCCL (the collective calls themselves excepted,
+ * this runs every kernel and every index list of the multi-GPU path on a single GPU). */
+int cgh_dist_group_start(cgh_dist **ranks, int nranks, const double *const *d_b, double *const *d_x, double tol, int iteration_capacity);
+int cgh_dist_group_iterate(cgh_dist **ranks, int nranks, int count);
+/* test/debug access to a rank's local block */
+int     cgh_dist_width(const cgh_dist *d);
+int64_t cgh_dist_halo(const cgh_dist *d);
+int     cgh_dist_download_local(const cgh_dist *d, double *diag, double *ell_vals, int *ell_cols);
+
 /* ---- timing helpers (benchmarks) ---------------------------------------- */
 /* Launch `reps` back-to-back SpMVs and return the average kernel time in ms (HIP events on the launch stream). */
 int cgh_time_spmv(const cgh_matrix *m, const double *d_x, double *d_y, int reps, double *ms_avg);
