@@ -122,6 +122,7 @@ def main():
     cga.init(local_rank)
 
     if world > 1 or args.dist:
+        cga.check(cga.lib().cgh_comm_preload(), "cgh_comm_preload")   # /opt/rocm's RCCL, before torch brings its own copy
         import bench_dist
         return bench_dist.run(args, rank, world, local_rank, (nx, ny, nz, points), SEED)
 

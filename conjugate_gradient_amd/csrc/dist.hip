@@ -51,7 +51,9 @@ struct rccl_api {
 int load_rccl()
 {
     if (g_rccl.handle) return CGH_OK;
-    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    // The ROCm installation's RCCL (the one this library's HIP runtime belongs to) first; a process that wants it
+    // must call cgh_comm_preload() before anything else loads another librccl.so.1 (e.g. before `import torch`).
+    const char *names[] = {"/opt/rocm/lib/librccl.so.1", "librccl.so.1", "librccl.so"};
     for (const char *nm : names) {
         g_rccl.handle = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
         if (g_rccl.handle) break;
@@ -302,6 +304,8 @@ int finish_neighbours(cgh_dist *d)
 extern "C" {
 
 // ------------------------------------------------------------------------------------------ communicator
+int cgh_comm_preload(void) { return load_rccl(); }
+
 int cgh_comm_unique_id(char out[256])
 {
     int rc = load_rccl();

@@ -169,6 +169,7 @@ int     cgh_partition_copy_local(const cgh_partition *p, double *diag, double *e
 /* RCCL bootstrap: rank 0 calls cgh_comm_unique_id, the 256 bytes (two ncclUniqueIds: one communicator for the
  * halo exchange, one for the all-reduces) travel to the other ranks by any means (bench.py:
  * torch.distributed/gloo broadcast), then every rank calls cgh_comm_init. */
+int cgh_comm_preload(void);   /* dlopen RCCL now (call before another copy of librccl gets loaded, e.g. before importing torch) */
 int cgh_comm_unique_id(char out_256_bytes[256]);
 int cgh_comm_init(int nranks, int rank, const char id_256_bytes[256]);
 void cgh_comm_destroy(void);

@@ -27,12 +27,7 @@ def _run_group(cga, ranks, bs, n_locs, g, check=8):
         step = min(check, mi - 1 - queued)
         cga.group_iterate(ranks, step)
         queued += step
-        cga.check(cga.lib().cgh_sync())
-        flags = set()
-        for r in ranks:
-            h = r.history(0, 1)           # forces a sync per rank; the flag is read through the history below
-        import ctypes as C
-        # all ranks carry the same flag (same reduced scalars): read rank 0's through its history
+        # all ranks carry the same flag (same reduced scalars): read it through rank 0's history
         hist = ranks[0].history(0, queued + 1)
         conv = np.nonzero(hist[1:, 0] < tol)[0]
         done = int(conv[0]) + 1 if conv.size else 0
