@@ -168,6 +168,12 @@ def main():
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "bytes_per_launch": int(alg_spmv), "ms_per_launch": spmv_ms, "traffic": None},
     }
+    # HBM traffic of the SpMV from the PMC counters: collected in separate rocprofv3 passes (it cannot be read live) and
+    # committed under profiles/ with its derivation; reported only for the workload it was measured on
+    tpath = os.path.join(ROOT, "profiles", "r01_traffic_%s.json" % args.workload)
+    if os.path.exists(tpath):
+        with open(tpath) as f:
+            out["roofline"]["traffic"] = json.load(f)["hbm_bytes_per_launch"]
     if not args.no_cpu_baseline:
         sv.free()
         out["cpu_baseline"] = cpu_baseline(A, b)
