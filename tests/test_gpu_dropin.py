@@ -247,3 +247,23 @@ def test_stdout_text_matches_reference(tag, mi, which):
     with open(os.path.join(foamio.GOLDEN, "stdout_%s_%s.txt" % (tag, which))) as f:
         want = f.read()
     assert out.stdout == want
+
+
+@pytest.mark.parametrize("fmt", ["ell", "coo", "csr"])
+def test_c_host_driver_end_to_end(fmt):
+    """conjugate_gradient_amd/host/test_cg_hip: the reference's `make test_cg` flow (tests/tests_cg.c:1061-1299) as a C
+    program over libcg_hip: file -> convert -> CG on the GPU -> compare with OpenFOAM's Phi (reference data/actual.txt:257-274)."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "conjugate_gradient_amd", "host", "test_cg_hip")
+    assert os.path.exists(exe), "build it with `make -C conjugate_gradient_amd/host` (done by __graft_entry__.build())"
+    env = dict(os.environ)
+    env.pop("CG_HIP_QUIET", None)
+    out = subprocess.run([exe, os.path.join(foamio.GOLDEN, "cylinder_2000.system"), os.path.join(foamio.GOLDEN, "Phi_2000"),
+                          "--format", fmt], capture_output=True, text=True, env=env, timeout=110)
+    assert out.returncode == 0, out.stderr[-2000:]
+    text = out.stdout
+    assert "Converged in 254 iterations." in text
+    assert "Iteration 252: Residual norm = 1.08951e-06" in text
+    assert "RMSE: 0.003061" in text and "Max component difference: 0.004555" in text
+    if fmt == "ell":
+        assert "nnz_max = 4" in text and "padding = 220 " in text          # SURVEY.md section 6: 8000 slots, 220 pads

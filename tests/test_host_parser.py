@@ -1,0 +1,50 @@
+"""CPU-only: the C parser of libcg_hip (include/parser.h, reference src/parser.c:29-177) against the numpy reader of the
+same fixtures."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import foamio
+
+
+@pytest.mark.parametrize("name", ["2000", "8000", "32k"])
+def test_parse_system_file(name):
+    import conjugate_gradient_amd as cga
+    L = cga.lib()
+    libc = C.CDLL(None)
+    libc.fopen.restype = C.c_void_p
+    libc.fopen.argtypes = [C.c_char_p, C.c_char_p]
+    libc.fclose.argtypes = [C.c_void_p]
+    libc.free.argtypes = [C.c_void_p]
+    for f in ("parseDoubleArray", "parseIntArray", "parseDoubleArraySolution"):
+        getattr(L, f).restype = C.c_void_p
+        getattr(L, f).argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_int)]
+    want = foamio.foam(name)
+    fp = libc.fopen(os.path.join(foamio.GOLDEN, "cylinder_%s.system" % name).encode(), b"r")
+    assert fp
+    got = {}
+    for key, fn, ctype in (("source", L.parseDoubleArray, C.c_double), ("diag", L.parseDoubleArray, C.c_double),
+                           ("upper", L.parseDoubleArray, C.c_double), ("upperAddr", L.parseIntArray, C.c_int),
+                           ("lowerAddr", L.parseIntArray, C.c_int)):
+        cnt = C.c_int(-1)
+        ptr = fn(fp, key.encode(), C.byref(cnt))
+        assert ptr and cnt.value >= 0, key
+        got[key] = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(ctype)), shape=(cnt.value,)).copy()
+        libc.free(ptr)
+    cnt = C.c_int(-1)
+    assert L.parseDoubleArray(fp, b"no_such_keyword", C.byref(cnt)) is None
+    libc.fclose(fp)
+    assert np.array_equal(got["source"], want["source"]) and np.array_equal(got["diag"], want["diag"])
+    assert np.array_equal(got["upper"], want["upper"])
+    assert np.array_equal(got["upperAddr"], want["cols"]) and np.array_equal(got["lowerAddr"], want["rows"])
+    if name == "2000":
+        fp = libc.fopen(os.path.join(foamio.GOLDEN, "Phi_2000").encode(), b"r")
+        cnt = C.c_int(-1)
+        ptr = L.parseDoubleArraySolution(fp, b"internalField   nonuniform List<scalar>", C.byref(cnt))
+        assert ptr and cnt.value == 2000
+        phi = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_double)), shape=(2000,)).copy()
+        libc.free(ptr)
+        libc.fclose(fp)
+        assert np.array_equal(phi, foamio.read_foam_field(os.path.join(foamio.GOLDEN, "Phi_2000")))
