@@ -57,6 +57,9 @@ def lib():
     L.cgh_matrix_from_coo_device.restype = vp
     L.cgh_matrix_poisson.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_int, vp]
     L.cgh_matrix_poisson.restype = vp
+    L.cgh_matrix_powerlaw.argtypes = [i64, C.c_int, C.c_uint64, C.c_int, vp]
+    L.cgh_matrix_powerlaw.restype = vp
+    L.cgh_matrix_min_row.argtypes = [vp]
     L.cgh_matrix_free.argtypes = [vp]
     L.cgh_matrix_free.restype = None
     for f in ("cgh_matrix_rows", "cgh_matrix_nnz_offdiag", "cgh_matrix_stored_bytes"):
@@ -207,6 +210,11 @@ class Matrix:
     def poisson(cls, nx, ny, nz, points, seed, layout=LAYOUT_ELL, b=None):
         return cls(lib().cgh_matrix_poisson(nx, ny, nz, points, seed, layout, b.ptr if b is not None else None))
 
+    @classmethod
+    def powerlaw(cls, n, max_len, seed, layout=LAYOUT_CSR, b=None):
+        return cls(lib().cgh_matrix_powerlaw(n, max_len, seed, layout, b.ptr if b is not None else None))
+
+    min_row = property(lambda self: lib().cgh_matrix_min_row(self.h))
     n = property(lambda self: lib().cgh_matrix_rows(self.h))
     K = property(lambda self: lib().cgh_matrix_width(self.h))
     nnz_offdiag = property(lambda self: lib().cgh_matrix_nnz_offdiag(self.h))

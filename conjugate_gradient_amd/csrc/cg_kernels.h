@@ -200,12 +200,32 @@ __global__ __launch_bounds__(CGH_BLOCK) void cg_update_p(int64_t n, const double
 // mode 2 (CG step B): rr, l1 -> res, beta, done flag; mode 3 (init): rr, l1 -> hist[0].
 constexpr int SEQ_CHUNK = 2048;
 
+// s = (((s + v[0]) + v[1]) + ...) + v[cnt-1], one lane.  The adds form one dependent chain; the LDS reads do not
+// depend on it, so they are issued 16 at a time (ds_read_b128) ahead of the adds that consume them.
+__device__ __forceinline__ double chain_add(double s, const double *v, int cnt)
+{
+    int j = 0;
+    for (; j + 16 <= cnt; j += 16) {
+        double t[16];
+#pragma unroll
+        for (int k = 0; k < 16; k += 2) {
+            const double2 w = *reinterpret_cast<const double2 *>(v + j + k);
+            t[k] = w.x;
+            t[k + 1] = w.y;
+        }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) s = add_rn(s, t[k]);
+    }
+    for (; j < cnt; ++j) s = add_rn(s, v[j]);
+    return s;
+}
+
 __global__ __launch_bounds__(CGH_BLOCK) void seq_sums(int64_t n, const double *__restrict__ a, const double *__restrict__ b,
                                                      const double *__restrict__ c, int mode, double *hist, int iter,
                                                      double tol, int *done, double *out)
 {
-    __shared__ double prod[SEQ_CHUNK];
-    __shared__ double absv[SEQ_CHUNK];
+    __shared__ __attribute__((aligned(16))) double prod[SEQ_CHUNK];
+    __shared__ __attribute__((aligned(16))) double absv[SEQ_CHUNK];
     if (done != nullptr && mode != 3 && mode != 0 && *done != 0) return;
     double s_dot = 0.0, s_l1 = 0.0;
     for (int64_t base = 0; base < n; base += SEQ_CHUNK) {
@@ -215,14 +235,8 @@ __global__ __launch_bounds__(CGH_BLOCK) void seq_sums(int64_t n, const double *_
             if (c != nullptr) absv[j] = fabs(c[base + j]);
         }
         __syncthreads();
-        if (threadIdx.x == 0) {
-            if (a != nullptr)
-                for (int j = 0; j < cnt; ++j) s_dot = add_rn(s_dot, prod[j]);
-        }
-        if (threadIdx.x == 64) {  // a second wave runs the second chain concurrently
-            if (c != nullptr)
-                for (int j = 0; j < cnt; ++j) s_l1 = add_rn(s_l1, absv[j]);
-        }
+        if (threadIdx.x == 0 && a != nullptr) s_dot = chain_add(s_dot, prod, cnt);
+        if (threadIdx.x == 64 && c != nullptr) s_l1 = chain_add(s_l1, absv, cnt);  // a second wave runs the second chain
         __syncthreads();
     }
     // hand s_l1 (wave 1) to thread 0

@@ -340,6 +340,20 @@ __global__ __launch_bounds__(256) void to_ell_rows(int64_t n, int K, int layout,
     }
 }
 
+__global__ __launch_bounds__(256) void min_row_length(int64_t n, const int64_t *__restrict__ row_ptr, int *result)
+{
+    int m = 0x7fffffff;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int len = (int)(row_ptr[i + 1] - row_ptr[i]);
+        m = len < m ? len : m;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const int o = __shfl_down(m, off, 64);
+        m = o < m ? o : m;
+    }
+    if ((threadIdx.x & 63) == 0) atomicMin(result, m);
+}
+
 struct dev_buf {
     void *p = nullptr;
     explicit dev_buf(size_t bytes) { p = cgh_alloc(bytes); }
@@ -558,6 +572,20 @@ int cgh_csr_to_ell_download(const cgh_matrix *m, double *ell_vals, int *ell_cols
 }
 
 extern "C" {
+
+// Shortest row (stored off-diagonals) of a CSR-layout matrix; -1 for other layouts.
+int cgh_matrix_min_row(const cgh_matrix *m)
+{
+    CGH_REQUIRE_READY(-1);
+    if (!m || m->layout != CGH_LAYOUT_CSR) return -1;
+    dev_buf r(sizeof(int));
+    if (!r.p) return -1;
+    int v = 0x7fffffff;
+    if (cgh_h2d(r.p, &v, sizeof v)) return -1;
+    hipLaunchKernelGGL(min_row_length, dim3(grid_for(m->n)), dim3(256), 0, g_cgh.stream, m->n, (const int64_t *)m->row_ptr, r.as<int>());
+    if (cgh_d2h(&v, r.p, sizeof v)) return -1;
+    return v;
+}
 
 cgh_matrix *cgh_matrix_from_coo_device(int64_t n, int64_t U, const double *d_diag, const double *d_upper, const int *d_rows,
                                        const int *d_cols, int layout)

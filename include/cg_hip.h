@@ -77,13 +77,16 @@ cgh_matrix *cgh_matrix_from_coo_device(int64_t n, int64_t nnz_upper, const doubl
                                        const int *d_rows, const int *d_cols, int layout);
 /* Seeded synthetic SPD matrices generated on the device (DESIGN.md "Generators"); d_b (may be NULL) receives the rhs. */
 cgh_matrix *cgh_matrix_poisson(int nx, int ny, int nz, int points /*7|27*/, uint64_t seed, int layout, double *d_b);
+/* Power-law (Pareto, exponent 2) row lengths 1..max_len (<= 2048), strictly diagonally dominant SPD (BASELINE config 5). */
+cgh_matrix *cgh_matrix_powerlaw(int64_t n, int max_len, uint64_t seed, int layout, double *d_b);
 void        cgh_matrix_free(cgh_matrix *m);
 
 int64_t cgh_matrix_rows(const cgh_matrix *m);
 int     cgh_matrix_width(const cgh_matrix *m);        /* K: max off-diagonals per row */
 int64_t cgh_matrix_nnz_offdiag(const cgh_matrix *m);  /* stored non-pad off-diagonals (= 2U) */
 int     cgh_matrix_layout(const cgh_matrix *m);
-int64_t cgh_matrix_stored_bytes(const cgh_matrix *m); /* HBM bytes of the matrix arrays incl. padding */
+int64_t cgh_matrix_stored_bytes(const cgh_matrix *m);
+int     cgh_matrix_min_row(const cgh_matrix *m);      /* shortest row of a CSR-layout matrix (-1 otherwise) */ /* HBM bytes of the matrix arrays incl. padding */
 /* Download as slot-major full ELL of width K=cgh_matrix_width (any layout); buffers hold n*K entries. */
 int     cgh_matrix_download_ell(const cgh_matrix *m, double *ell_vals, int *ell_cols);
 int     cgh_matrix_download_diag(const cgh_matrix *m, double *diag);

@@ -108,3 +108,34 @@ def poisson_coo(nx, ny, nz, seed, points=7):
     diag = float(points - 1) + 1e-3 * hash01(seed, idx)
     b = hash01(seed + 1, idx) - 0.5
     return dict(n=n, U=int(rows.size), diag=diag, upper=upper, rows=rows, cols=cols, source=b)
+
+
+def hash64(seed, idx):
+    with np.errstate(over="ignore"):
+        z = np.uint64(seed) ^ (np.asarray(idx, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15))
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return z ^ (z >> np.uint64(31))
+
+
+def powerlaw_coo(n, max_len, seed):
+    """numpy twin of cgh_matrix_powerlaw's upper-triangular COO (generate.hip): row-sorted, generation order inside a
+    row, duplicates dropped (first kept).  The diagonal (1 + sum |a_ij| in the row's stored order) is the caller's job."""
+    rows, cols, vals = [], [], []
+    u = hash01(seed, np.arange(n))
+    with np.errstate(divide="ignore"):
+        L = np.where(u > 0, np.floor(1.0 / np.where(u > 0, u, 1.0)), max_len)
+    L = np.clip(L, 1, max_len).astype(np.int64)
+    m = np.minimum((L + 1) // 2, n - np.arange(n) - 1)
+    for i in range(n):
+        if m[i] <= 0:
+            continue
+        t = np.arange(m[i], dtype=np.uint64)
+        c = i + 1 + (hash64(seed + 1, np.uint64(i) * np.uint64(2048) + t) % np.uint64(n - i - 1)).astype(np.int64)
+        _, first = np.unique(c, return_index=True)
+        keep = np.sort(first)
+        rows.append(np.full(keep.size, i, dtype=np.int32))
+        cols.append(c[keep].astype(np.int32))
+        vals.append(-hash01(seed + 2, np.uint64(i) * np.uint64(2048) + t[keep]))
+    return dict(n=n, rows=np.concatenate(rows), cols=np.concatenate(cols), upper=np.concatenate(vals),
+                source=hash01(seed + 3, np.arange(n)) - 0.5)

@@ -112,3 +112,55 @@ def test_blas1(cga):
         cga.binding.check(cga.lib().cgh_axpy(da.ptr, db.ptr, 2.5, da.ptr, n))   # out aliases a (cg.c:467)
         O.lib().orc_vec_axpy(O.D(a), O.D(b), 2.5, O.D(want), n)
         assert np.array_equal(bits(da.to_host()), bits(want))
+
+
+def test_full_size_256cubed_trajectory_vs_reference_cpu(cga):
+    """BASELINE config 3 at full size (16.7M rows): the throughput-mode trajectory against the reference's own
+    arithmetic on the host (oracle/_ref/libref.so = the reference compiled from its sources; falls back to the oracle
+    port), for the first iterations -- within 1e-10 relative (north_star's bar), SpMV bit-exact."""
+    import ctypes as C
+    import os
+    N, iters = 256, 12
+    n = N ** 3
+    b = cga.DeviceVector(n); x = cga.DeviceVector(n); y = cga.DeviceVector(n)
+    A = cga.Matrix.poisson(N, N, N, 7, 0x5EED0001, cga.LAYOUT_ELL, b)
+    ev, ec = A.download_ell(); diag = A.download_diag(); bh = b.to_host()
+    K = A.K
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    ref_so = os.path.join(root, "oracle", "_ref", "libref.so")
+    yr = np.empty(n)
+    if os.path.exists(ref_so):
+        R = C.CDLL(ref_so)
+        R.vec_dot.restype = C.c_double; R.vec_l1norm.restype = C.c_double
+        R.vec_axpy.argtypes = [O.dp, O.dp, C.c_double, O.dp, C.c_int]
+        mv = lambda v, out: R.mv_ell_symmetric_full_colmajor(n, K, O.D(diag), O.D(ev), O.I(ec), O.D(v), O.D(out))
+        dot = lambda u, v: R.vec_dot(O.D(u), O.D(v), n)
+        l1 = lambda u: R.vec_l1norm(O.D(u), n)
+        axpy = lambda a_, b_, al, out: R.vec_axpy(O.D(a_), O.D(b_), al, O.D(out), n)
+    else:
+        L = O.lib()
+        mv = lambda v, out: L.orc_mv_ell_symmetric_full_colmajor(n, K, O.D(diag), O.D(ev), O.I(ec), O.D(v), O.D(out))
+        dot = lambda u, v: L.orc_vec_dot(O.D(u), O.D(v), n)
+        l1 = lambda u: L.orc_vec_l1norm(O.D(u), n)
+        axpy = lambda a_, b_, al, out: L.orc_vec_axpy(O.D(a_), O.D(b_), al, O.D(out), n)
+    # SpMV at full size: bit-exact
+    mv(bh, yr)
+    A.spmv(b, y)
+    assert np.array_equal(bits(y.to_host()), bits(yr))
+    # reference loop (cg.c:414-508) on the host for `iters` iterations
+    xr = np.zeros(n); r = bh.copy(); p = bh.copy(); Ap = np.empty(n)
+    rr = dot(r, r)
+    want = [l1(r) / 2.0]
+    for _ in range(iters):
+        mv(p, Ap)
+        alpha = rr / dot(p, Ap)
+        axpy(xr, p, alpha, xr); axpy(r, Ap, -alpha, r)
+        rr_new = dot(r, r)
+        want.append(l1(r) / 2.0)
+        axpy(r, p, rr_new / rr, p)
+        rr = rr_new
+    rep, hist = cga.cg_solve(A, b, x, fixed_iters=iters)
+    rel = np.abs(hist[:, 0] - np.array(want)) / np.array(want)
+    print("\\n[256^3 throughput-mode vs reference CPU, %d iterations] max rel dev %.3e" % (iters, rel.max()))
+    assert rel.max() < 1e-10
+    assert np.abs(x.to_host() - xr).max() <= 1e-10 * np.abs(xr).max()

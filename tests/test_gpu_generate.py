@@ -34,3 +34,31 @@ def test_poisson_ell_matches_reference_conversion(cga, shape):
         assert st == 0 and np.array_equal(gc, ec) and np.array_equal(bits(gv), bits(ev))
     assert np.array_equal(bits(A.download_diag()), bits(s["diag"]))
     assert np.array_equal(bits(b.to_host()), bits(s["source"]))
+
+
+@pytest.mark.parametrize("layout", [1, 2, 0])
+def test_powerlaw_generator(cga, layout):
+    n, max_len, seed = 6000, 300, 0x5EED0005
+    s = foamio.powerlaw_coo(n, max_len, seed)
+    K = O.max_nnz_full(n, s["rows"], s["cols"])
+    ev, ec, st = O.coo_to_ell_full(n, s["upper"], s["rows"], s["cols"], K)
+    assert st == 0 and K > 64
+    diag = np.ones(n)
+    for slot in range(K):                                   # 1 + sum |a_ij| in the row's stored order
+        diag = diag + np.abs(ev[slot * n:(slot + 1) * n])
+    b = cga.DeviceVector(n)
+    A = cga.Matrix.powerlaw(n, max_len, seed, layout, b)
+    assert (A.n, A.K, A.nnz_offdiag) == (n, K, 2 * s["rows"].size)
+    gv, gc = A.download_ell()
+    assert np.array_equal(gc, ec) and np.array_equal(bits(gv), bits(ev))
+    assert np.array_equal(bits(A.download_diag()), bits(diag))
+    assert np.array_equal(bits(b.to_host()), bits(s["source"]))
+    # SPD by strict diagonal dominance: CG converges fast; strict mode equals the oracle on the same arrays
+    x = cga.DeviceVector(n)
+    rep, hist = cga.cg_solve(A, b, x, max_iter=200, tol=1e-8, strict=1 if layout != 1 else 0)
+    ret, xo, traj = O.cg(O.FMT_ELL_FULL, n, diag, 0, ev, ec, None, K, s["source"], 200, 1e-8)
+    assert ret > 0 and abs(rep.ret - ret) <= 1
+    if layout != 1:                                          # CSR sums rows longer than 64 entries in tree order
+        assert np.array_equal(bits(x.to_host()), bits(xo))
+    else:
+        assert np.abs(x.to_host() - xo).max() < 1e-9
