@@ -87,6 +87,10 @@ __global__ __launch_bounds__(CGH_BLOCK) void cg_update_xr(int64_t n, double *__r
     constexpr bool STRICT = MODE == 1;
     __shared__ double lds[4];
     if (*done != 0) return;
+    // iter == 0: take the iteration number from the device (done[2] = last iteration finished by cg_update_p), so that
+    // identical launches can be replayed from a HIP graph; done[1] tells cg_update_p which iteration this is
+    if (iter == 0) iter = done[2] + 1;
+    if (blockIdx.x == 0 && threadIdx.x == 0) const_cast<int *>(done)[1] = iter;
     double alpha;
     if constexpr (MODE == 1) {
         alpha = hist[(size_t)iter * HIST + 2];
@@ -150,6 +154,8 @@ __global__ __launch_bounds__(CGH_BLOCK) void cg_update_p(int64_t n, const double
     constexpr bool STRICT = MODE == 1;
     __shared__ double lds[4];
     if (*done != 0) return;
+    if (iter == 0) iter = done[1];
+    if (blockIdx.x == 0 && threadIdx.x == 0) done[2] = iter;
     double beta;
     bool   conv;
     if constexpr (MODE == 1) {
@@ -227,6 +233,8 @@ __global__ __launch_bounds__(CGH_BLOCK) void seq_sums(int64_t n, const double *_
     __shared__ __attribute__((aligned(16))) double prod[SEQ_CHUNK];
     __shared__ __attribute__((aligned(16))) double absv[SEQ_CHUNK];
     if (done != nullptr && mode != 3 && mode != 0 && *done != 0) return;
+    if (iter == 0 && mode == 1) iter = done[2] + 1;   // before cg_update_xr of this iteration
+    if (iter == 0 && mode == 2) iter = done[1];       // after it
     double s_dot = 0.0, s_l1 = 0.0;
     for (int64_t base = 0; base < n; base += SEQ_CHUNK) {
         const int cnt = (int)((n - base) < SEQ_CHUNK ? (n - base) : SEQ_CHUNK);

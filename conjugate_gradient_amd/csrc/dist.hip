@@ -26,6 +26,8 @@
 
 int cgh_launch_spmv_ell_range(const cgh_matrix *m, const double *x, double *y, double *dot_partials, int *grid_out,
                               const int *done, hipStream_t s, int64_t rb, int64_t re);
+int cgh_launch_spmv_ell_range2(const cgh_matrix *m, const double *x, double *y, double *dot_partials, int *grid_out,
+                               const int *done, hipStream_t s, int64_t rb, int64_t re, int64_t rb2, int64_t re2);
 
 // ------------------------------------------------------------------------------------- RCCL, loaded lazily
 namespace {
@@ -257,10 +259,7 @@ int spmv_ranges(cgh_dist *d, bool interior, bool boundary, bool with_dot, int *c
         *count_io += g;
     }
     if (boundary) {
-        rc = cgh_launch_spmv_ell_range(&d->mat, d->p, d->Ap, with_dot ? d->partA + *count_io : nullptr, &g, done, s, 0, a);
-        if (rc) return rc;
-        *count_io += g;
-        rc = cgh_launch_spmv_ell_range(&d->mat, d->p, d->Ap, with_dot ? d->partA + *count_io : nullptr, &g, done, s, b, nl);
+        rc = cgh_launch_spmv_ell_range2(&d->mat, d->p, d->Ap, with_dot ? d->partA + *count_io : nullptr, &g, done, s, 0, a, b, nl);
         if (rc) return rc;
         *count_io += g;
     }
@@ -589,12 +588,12 @@ int cgh_dist_poll(cgh_dist *d, int *done_iter, int *queued)
     hipStream_t s = g_cgh.stream;
     // every rank derives the flag from the same reduced scalars; the max-reduce makes agreement explicit, so that
     // all ranks stop queueing (collectives!) at the same poll
-    if (g_rccl.comm && d->nranks > 1) CGH_NCCL(g_rccl.AllReduce(d->done, d->done + 1, 1, ncclInt32, ncclMax, g_rccl.comm, s));
-    int v[2] = {0, 0};
-    CGH_HIP(hipMemcpyAsync(v, d->done, sizeof(int) * 2, hipMemcpyDeviceToHost, s));
+    if (g_rccl.comm && d->nranks > 1) CGH_NCCL(g_rccl.AllReduce(d->done, d->done + 3, 1, ncclInt32, ncclMax, g_rccl.comm, s));
+    int v[4] = {0, 0, 0, 0};  // [0] this rank's flag, [1],[2] iteration counters (cg_kernels.h), [3] max over ranks
+    CGH_HIP(hipMemcpyAsync(v, d->done, sizeof(int) * 4, hipMemcpyDeviceToHost, s));
     CGH_HIP(hipStreamSynchronize(s));
     CGH_HIP(hipStreamSynchronize(g_cgh.comm_stream));
-    if (done_iter) *done_iter = (g_rccl.comm && d->nranks > 1) ? v[1] : v[0];
+    if (done_iter) *done_iter = (g_rccl.comm && d->nranks > 1) ? v[3] : v[0];
     if (queued) *queued = d->queued;
     return CGH_OK;
 }

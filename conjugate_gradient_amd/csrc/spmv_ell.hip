@@ -42,13 +42,17 @@ __global__ __launch_bounds__(CGH_BLOCK) void spmv_ell_r2(int64_t n, int Krt, con
                                                         const double *__restrict__ vals, const int *__restrict__ cols,
                                                         const double *__restrict__ x, double *__restrict__ y,
                                                         double *__restrict__ partials, const int *__restrict__ done,
-                                                        int rev, int64_t row_begin, int64_t row_end)
+                                                        int rev, int64_t row_begin, int64_t row_end, int64_t row_begin2,
+                                                        int64_t row_end2)
 {
     __shared__ double lds[4];
     if (done != nullptr && *done != 0) return;
     const int     K = KT > 0 ? KT : Krt;
-    const int64_t pair0 = row_begin >> 1;              // rows [row_begin,row_end): both even on this path
-    const int64_t pairs = (row_end >> 1) - pair0;
+    // rows [row_begin,row_end) followed by rows [row_begin2,row_end2) (all four even on this path): one launch serves the
+    // two boundary row ranges of a multi-GPU block
+    const int64_t pair0 = row_begin >> 1, pairs1 = (row_end >> 1) - pair0;
+    const int64_t pair0b = row_begin2 >> 1;
+    const int64_t pairs = pairs1 + ((row_end2 >> 1) - pair0b);
     double        local = 0.0;
 
     // Tile walk.  Workgroup-iteration j (= blockIdx + k*gridDim, gridDim a multiple of 8) runs on XCD
@@ -65,7 +69,7 @@ __global__ __launch_bounds__(CGH_BLOCK) void spmv_ell_r2(int64_t n, int Krt, con
         const int64_t t = REMAP ? ((q >> 3) << 6) + ((j & 7) << 3) + (q & 7) : j;
         const int64_t pr = t * CGH_BLOCK + threadIdx.x;
         if (pr >= pairs) continue;
-        const int64_t i0 = (pair0 + pr) << 1;
+        const int64_t i0 = (pr < pairs1 ? pair0 + pr : pair0b + (pr - pairs1)) << 1;
         const double2 d = *reinterpret_cast<const double2 *>(diag + i0);
         const double2 xi = *reinterpret_cast<const double2 *>(x + i0);
         double        a0 = add_rn(0.0, mul_rn(d.x, xi.x));
@@ -160,12 +164,12 @@ inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 template <bool DOT, int VAR>
 void launch_r2(int K, int grid, hipStream_t s, int64_t n, const double *diag, const double *vals, const int *cols,
-               const double *x, double *y, double *partials, const int *done, int64_t rb, int64_t re)
+               const double *x, double *y, double *partials, const int *done, int64_t rb, int64_t re, int64_t rb2, int64_t re2)
 {
 #define CGH_ELL_CASE(KK)                                                                                       \
     case KK:                                                                                                   \
         hipLaunchKernelGGL((spmv_ell_r2<KK, DOT, VAR>), dim3(grid), dim3(CGH_BLOCK), 0, s, n, K, diag, vals, cols, x, y, \
-                           partials, done, g_cgh.sweep_reverse, rb, re);                                                                    \
+                           partials, done, g_cgh.sweep_reverse, rb, re, rb2, re2);                                                                    \
         break;
     switch (K) {
         CGH_ELL_CASE(1)
@@ -180,7 +184,7 @@ void launch_r2(int K, int grid, hipStream_t s, int64_t n, const double *diag, co
         CGH_ELL_CASE(26)
     default:
         hipLaunchKernelGGL((spmv_ell_r2<0, DOT, VAR>), dim3(grid), dim3(CGH_BLOCK), 0, s, n, K, diag, vals, cols, x, y,
-                           partials, done, g_cgh.sweep_reverse, rb, re);
+                           partials, done, g_cgh.sweep_reverse, rb, re, rb2, re2);
     }
 #undef CGH_ELL_CASE
 }
@@ -205,14 +209,36 @@ static int ell_grid_rows(int64_t rows)
 
 int cgh_ell_grid(const cgh_matrix *m) { return ell_grid_rows(m->n); }
 
+int cgh_launch_spmv_ell_range2(const cgh_matrix *m, const double *x, double *y, double *dot_partials, int *grid_out,
+                               const int *done, hipStream_t s, int64_t rb, int64_t re, int64_t rb2, int64_t re2);
+
 // y[rb:re) = (A x)[rb:re).  The slot stride is m->n; x may be longer than n (multi-GPU: halo entries follow the owned ones).
 int cgh_launch_spmv_ell_range(const cgh_matrix *m, const double *x, double *y, double *dot_partials, int *grid_out,
                               const int *done, hipStream_t s, int64_t rb, int64_t re)
 {
-    const int grid = ell_grid_rows(re - rb);
-    if (grid_out) *grid_out = re > rb ? grid : 0;
-    if (re <= rb) return CGH_OK;
-    if (ell_vector_path(m, x, y) && rb % 2 == 0 && re % 2 == 0) {
+    return cgh_launch_spmv_ell_range2(m, x, y, dot_partials, grid_out, done, s, rb, re, 0, 0);
+}
+
+// Two row ranges in one launch (second may be empty).
+int cgh_launch_spmv_ell_range2(const cgh_matrix *m, const double *x, double *y, double *dot_partials, int *grid_out,
+                               const int *done, hipStream_t s, int64_t rb, int64_t re, int64_t rb2, int64_t re2)
+{
+    if (re < rb) re = rb;
+    if (re2 < rb2) re2 = rb2;
+    const int64_t rows = (re - rb) + (re2 - rb2);
+    const int grid = ell_grid_rows(rows);
+    if (grid_out) *grid_out = rows > 0 ? grid : 0;
+    if (rows <= 0) return CGH_OK;
+    if (!(ell_vector_path(m, x, y) && rb % 2 == 0 && re % 2 == 0 && rb2 % 2 == 0 && re2 % 2 == 0) && re2 > rb2) {
+        // scalar path: one launch per range
+        int g1 = 0, g2 = 0;
+        int rc = cgh_launch_spmv_ell_range2(m, x, y, dot_partials, &g1, done, s, rb, re, 0, 0);
+        if (rc) return rc;
+        rc = cgh_launch_spmv_ell_range2(m, x, y, dot_partials ? dot_partials + g1 : nullptr, &g2, done, s, rb2, re2, 0, 0);
+        if (grid_out) *grid_out = g1 + g2;
+        return rc;
+    }
+    if (ell_vector_path(m, x, y) && rb % 2 == 0 && re % 2 == 0 && rb2 % 2 == 0 && re2 % 2 == 0) {
         static const int var = [] {
             const int v = getenv("CGH_ELL_VARIANT") ? atoi(getenv("CGH_ELL_VARIANT")) : VAR_DEFAULT;
             return (v == 0 || v == 1 || v == 2 || v == 3 || v == 7 || v == 11) ? v : VAR_DEFAULT;
@@ -220,9 +246,9 @@ int cgh_launch_spmv_ell_range(const cgh_matrix *m, const double *x, double *y, d
 #define CGH_ELL_VAR(V)                                                                                                  \
     case V:                                                                                                             \
         if (dot_partials)                                                                                               \
-            launch_r2<true, V>(m->K, grid, s, m->n, m->diag, m->vals, m->cols, x, y, dot_partials, done, rb, re);       \
+            launch_r2<true, V>(m->K, grid, s, m->n, m->diag, m->vals, m->cols, x, y, dot_partials, done, rb, re, rb2, re2); \
         else                                                                                                            \
-            launch_r2<false, V>(m->K, grid, s, m->n, m->diag, m->vals, m->cols, x, y, nullptr, done, rb, re);           \
+            launch_r2<false, V>(m->K, grid, s, m->n, m->diag, m->vals, m->cols, x, y, nullptr, done, rb, re, rb2, re2); \
         break;
         switch (var) {
             CGH_ELL_VAR(0)

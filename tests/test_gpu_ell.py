@@ -164,3 +164,18 @@ def test_full_size_256cubed_trajectory_vs_reference_cpu(cga):
     print("\\n[256^3 throughput-mode vs reference CPU, %d iterations] max rel dev %.3e" % (iters, rel.max()))
     assert rel.max() < 1e-10
     assert np.abs(x.to_host() - xr).max() <= 1e-10 * np.abs(xr).max()
+
+
+@pytest.mark.parametrize("strict", [0, 1])
+def test_graph_replay_matches_eager(cga, strict, monkeypatch):
+    """CGH_GRAPH=1: batches of iterations replayed from a HIP graph (device-side iteration counter) give the same bits"""
+    s, g = inputs("cylinder_8000"), golden("cylinder_8000")
+    n, K = s["n"], int(g["K_full"])
+    A = cga.Matrix.from_ell(n, K, s["diag"], g["ell_full_vals"], g["ell_full_cols"])
+    b = cga.DeviceVector.from_host(s["source"]); x = cga.DeviceVector(n); x2 = cga.DeviceVector(n)
+    monkeypatch.setenv("CGH_GRAPH", "0")
+    rep, hist = cga.cg_solve(A, b, x, max_iter=1000, tol=1e-6, strict=strict, check_every=32)
+    monkeypatch.setenv("CGH_GRAPH", "1")
+    rep2, hist2 = cga.cg_solve(A, b, x2, max_iter=1000, tol=1e-6, strict=strict, check_every=32)
+    assert rep2.ret == rep.ret and same_bits_nan(hist2, hist)
+    assert np.array_equal(bits(x2.to_host()), bits(x.to_host()))
