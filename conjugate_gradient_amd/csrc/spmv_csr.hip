@@ -8,7 +8,8 @@
 // bit -- and needs no atomics.
 //
 // CSR "stream/adaptive" kernel (skewed row lengths, BASELINE config 5): rows are grouped into row blocks
-// whose entries start inside one 2048-entry window.  A workgroup streams the block's values/columns
+// whose entries start inside one 1024-entry window (CGH_CSR_WINDOW; measured 256^3 7-point: 3.18 / 3.98 / 1.92 TB/s at
+// 512 / 1024 / 2048).  A workgroup streams the block's values/columns
 // with coalesced non-temporal loads, forms the rounded products v*x[col] into LDS, then
 //   * rows of <= 64 entries: one lane adds the row's products left to right (bit-exact order);
 //   * longer rows: a wave adds strided partial sums and combines them with a shuffle tree (NOT the
@@ -22,11 +23,21 @@ int cgh_exclusive_scan_i32_to_i64(const int *d_in, int64_t *d_out, int64_t count
 
 namespace {
 
-constexpr int CSR_WINDOW = 2048;             // entries per row-block window
-constexpr int CSR_LDS = 2 * CSR_WINDOW;      // a block's rows start in one window and the last may run one window over
+// entries per row-block window (a block's rows start in one window and the last may run one window over, so the LDS
+// stage holds 2*window products): 1024 -> 16 KB of LDS per workgroup, 8 workgroups per CU
+constexpr int CSR_WINDOW_DEFAULT = 1024;
 constexpr int CSR_WAVE_ROW = 64;             // rows longer than this are summed by a wave
 
-__global__ __launch_bounds__(256) void flag_row_blocks(int64_t n, const int64_t *__restrict__ row_ptr, int *__restrict__ flag)
+int csr_window()
+{
+    static const int w = [] {
+        const int v = getenv("CGH_CSR_WINDOW") ? atoi(getenv("CGH_CSR_WINDOW")) : CSR_WINDOW_DEFAULT;
+        return (v == 512 || v == 1024 || v == 2048) ? v : CSR_WINDOW_DEFAULT;
+    }();
+    return w;
+}
+
+__global__ __launch_bounds__(256) void flag_row_blocks(int64_t n, const int64_t *__restrict__ row_ptr, int *__restrict__ flag, int CSR_WINDOW)
 {
     for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < n; r += (int64_t)gridDim.x * 256) {
         int f = 0;
@@ -51,13 +62,14 @@ __global__ __launch_bounds__(256) void compact_row_blocks(int64_t n, const int *
     }
 }
 
-template <bool DOT>
+template <bool DOT, int CSR_WINDOW>
 __global__ __launch_bounds__(CGH_BLOCK) void spmv_csr_stream(int64_t nblocks, const int *__restrict__ blocks,
                                                             const int64_t *__restrict__ row_ptr, const double *__restrict__ diag,
                                                             const double *__restrict__ vals, const int *__restrict__ cols,
                                                             const double *__restrict__ x, double *__restrict__ y,
                                                             double *__restrict__ partials, const int *__restrict__ done, int exact)
 {
+    constexpr int CSR_LDS = 2 * CSR_WINDOW;
     __shared__ double prod[CSR_LDS];
     __shared__ double red[4];
     if (done != nullptr && *done != 0) return;
@@ -94,7 +106,7 @@ __global__ __launch_bounds__(CGH_BLOCK) void spmv_csr_stream(int64_t nblocks, co
             const double xr = x[r];
             double       acc = add_rn(0.0, mul_rn(diag[r], xr));
             for (int q = q0; q < q1; ++q) acc = add_rn(acc, prod[q]);
-            y[r] = acc;
+            __builtin_nontemporal_store(acc, y + r);
             if (DOT) local += xr * acc;
         }
         if (!exact && __syncthreads_or(any_long)) {
@@ -146,7 +158,7 @@ __global__ __launch_bounds__(CGH_BLOCK) void spmv_sell64(int64_t n, int64_t nsli
             const double tt = madd_rn(acc, v, g);
             acc = c >= 0 ? tt : acc;
         }
-        y[r] = acc;
+        __builtin_nontemporal_store(acc, y + r);
         if (DOT) local += xr * acc;
     }
     if constexpr (DOT) {
@@ -169,7 +181,8 @@ int cgh_csr_build_row_blocks(cgh_matrix *m, hipStream_t s)
     if (rc == CGH_OK) {
         const int g = cgh_stream_grid((n + 255) / 256, 8);
         if (hipMemsetAsync(flag + n, 0, sizeof(int), s) != hipSuccess) rc = CGH_EHIP;
-        hipLaunchKernelGGL(flag_row_blocks, dim3(g), dim3(256), 0, s, n, (const int64_t *)m->row_ptr, flag);
+        hipLaunchKernelGGL(flag_row_blocks, dim3(g), dim3(256), 0, s, n, (const int64_t *)m->row_ptr, flag, csr_window());
+        m->bin_start[1] = csr_window();
         if (rc == CGH_OK) rc = cgh_exclusive_scan_i32_to_i64(flag, pos, n + 1, s);
         if (rc == CGH_OK && (hipMemcpyAsync(&nblocks, pos + n, sizeof(int64_t), hipMemcpyDeviceToHost, s) != hipSuccess ||
                              hipStreamSynchronize(s) != hipSuccess))
@@ -191,21 +204,32 @@ int cgh_csr_build_row_blocks(cgh_matrix *m, hipStream_t s)
     return rc;
 }
 
-int cgh_launch_spmv_csr(const cgh_matrix *m, const double *x, double *y, double *dot_partials, int *grid_out,
-                        const int *done, hipStream_t s)
+template <int W>
+static void launch_csr(const cgh_matrix *m, const double *x, double *y, double *dot_partials, const int *done, hipStream_t s, int grid,
+                       int exact)
 {
-    static const int exact = getenv("CGH_CSR_EXACT") ? atoi(getenv("CGH_CSR_EXACT")) : 0;
-    const int64_t    nb = m->bin_start[0];
-    const int        grid = cgh_stream_grid(nb, 6);
-    if (grid_out) *grid_out = grid;
+    const int64_t nb = m->bin_start[0];
     if (dot_partials)
-        hipLaunchKernelGGL(spmv_csr_stream<true>, dim3(grid), dim3(CGH_BLOCK), 0, s, nb, (const int *)m->bin_rows,
+        hipLaunchKernelGGL((spmv_csr_stream<true, W>), dim3(grid), dim3(CGH_BLOCK), 0, s, nb, (const int *)m->bin_rows,
                            (const int64_t *)m->row_ptr, (const double *)m->diag, (const double *)m->vals, (const int *)m->cols, x, y,
                            dot_partials, done, exact);
     else
-        hipLaunchKernelGGL(spmv_csr_stream<false>, dim3(grid), dim3(CGH_BLOCK), 0, s, nb, (const int *)m->bin_rows,
+        hipLaunchKernelGGL((spmv_csr_stream<false, W>), dim3(grid), dim3(CGH_BLOCK), 0, s, nb, (const int *)m->bin_rows,
                            (const int64_t *)m->row_ptr, (const double *)m->diag, (const double *)m->vals, (const int *)m->cols, x, y,
                            (double *)nullptr, done, exact);
+}
+
+int cgh_launch_spmv_csr(const cgh_matrix *m, const double *x, double *y, double *dot_partials, int *grid_out,
+                        const int *done, hipStream_t s)
+{
+    const int     exact = getenv("CGH_CSR_EXACT") ? atoi(getenv("CGH_CSR_EXACT")) : 0;
+    const int64_t nb = m->bin_start[0];
+    const int     w = (int)m->bin_start[1];   // the window the row blocks were built for
+    const int     grid = cgh_stream_grid(nb, w <= 1024 ? 8 : 5);
+    if (grid_out) *grid_out = grid;
+    if (w == 512) launch_csr<512>(m, x, y, dot_partials, done, s, grid, exact);
+    else if (w == 2048) launch_csr<2048>(m, x, y, dot_partials, done, s, grid, exact);
+    else launch_csr<1024>(m, x, y, dot_partials, done, s, grid, exact);
     CGH_HIP(hipGetLastError());
     return CGH_OK;
 }
