@@ -267,3 +267,52 @@ def test_c_host_driver_end_to_end(fmt):
     assert "RMSE: 0.003061" in text and "Max component difference: 0.004555" in text
     if fmt == "ell":
         assert "nnz_max = 4" in text and "padding = 220 " in text          # 8000 slots, 220 pads
+
+
+def _coo_solve(api, n, diag, upper, rows, cols, b, max_iter=1000, tol=1e-6):
+    x = np.full(n, 5.0)
+    e = np.zeros(0, dtype=np.int32)
+    ret = api.conjugate_gradient_coo(n, D(diag), rows.size, D(upper) if upper.size else None,
+                                     I(rows) if rows.size else None, I(cols) if cols.size else None, D(b), D(x), max_iter, tol)
+    oret, ox, traj = O.cg(O.FMT_COO, n, diag, rows.size, upper if upper.size else np.zeros(1),
+                          rows if rows.size else np.zeros(1, dtype=np.int32), cols if cols.size else np.zeros(1, dtype=np.int32),
+                          0, b, max_iter, tol)
+    return ret, x, oret, ox
+
+
+def test_reference_toy_cases(api):
+    """the reference's toy drivers (tests/tests_cg.c:14-249): zero matrix, identity, dense uniform 1/n -- they only print
+    there; here the oracle supplies the expected return value and x"""
+    n = 2000
+    e = np.zeros(0, dtype=np.int32); ev = np.zeros(0)
+    b = np.arange(1, n + 1, dtype=np.float64)
+    # zero matrix with NULL upper/rows/cols (tests_cg.c:20-46): p.Ap = 0 -> alpha = inf, NaNs, never converges
+    ret, x, oret, ox = _coo_solve(api, n, np.zeros(n), ev, e, e, b)
+    assert ret == oret == -1 and np.array_equal(np.isnan(x), np.isnan(ox)) and np.isnan(x).all()
+    # identity (tests_cg.c:89-121): one step
+    ret, x, oret, ox = _coo_solve(api, n, np.ones(n), ev, e, e, b)
+    assert ret == oret == 2 and np.array_equal(bits(x), bits(ox)) and np.array_equal(x, b)
+    # dense uniform 1/n (tests_cg.c:163-212), smaller n to keep the test quick: rank-1 matrix, row width n-1
+    m = 300
+    iu = np.triu_indices(m, 1)
+    rows = iu[0].astype(np.int32); cols = iu[1].astype(np.int32)
+    ret, x, oret, ox = _coo_solve(api, m, np.full(m, 1.0 / m), np.full(rows.size, 1.0 / m), rows, cols, np.ones(m))
+    assert ret == oret and np.array_equal(bits(x), bits(ox))
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 5, 7, 64, 65, 511])
+def test_tiny_and_odd_sizes(api, n):
+    rng = np.random.default_rng(n)
+    rows, cols = (np.zeros(0, dtype=np.int32),) * 2
+    if n > 1:
+        iu = np.triu_indices(n, 1)
+        keep = rng.random(iu[0].size) < min(1.0, 6.0 / n)
+        rows = iu[0][keep].astype(np.int32); cols = iu[1][keep].astype(np.int32)
+    upper = -rng.random(rows.size)
+    diag = np.full(n, 1.0)
+    np.add.at(diag, rows, -upper); np.add.at(diag, cols, -upper)
+    b = rng.standard_normal(n)
+    for mi, tol in ((1000, 1e-6), (1, 1e-6), (2, 1e-6), (3, 0.0), (50, 1e300)):
+        ret, x, oret, ox = _coo_solve(api, n, diag, upper, rows, cols, b, mi, tol)
+        assert ret == oret, (n, mi, tol, ret, oret)
+        assert np.array_equal(bits(x), bits(ox)), (n, mi, tol)
