@@ -238,7 +238,7 @@ static int enqueue_iterations(cgh_solver *sv, int count, int time_kernels, bool 
             hipLaunchKernelGGL((cg_update_p<1, 3>), dim3(vg), dim3(CGH_BLOCK), 0, s, n, (const double *)dr, dp,
                                (const double *)dB, vg, dh, iter, tol, dd, rev1, (const double *)nullptr);
         } else {
-            static const int vv = getenv("CGH_VEC_VARIANT") ? atoi(getenv("CGH_VEC_VARIANT")) & 3 : 3;
+            static const int vv = getenv("CGH_VEC_VARIANT") ? atoi(getenv("CGH_VEC_VARIANT")) & 15 : 3;
 #define CGH_VEC_VAR(V)                                                                                                 \
     case V:                                                                                                            \
         hipLaunchKernelGGL((cg_update_xr<0, V>), dim3(vg), dim3(CGH_BLOCK), 0, s, n, d_x, (const double *)dp, dr,  \
@@ -249,8 +249,13 @@ static int enqueue_iterations(cgh_solver *sv, int count, int time_kernels, bool 
             switch (vv) {
                 CGH_VEC_VAR(0)
                 CGH_VEC_VAR(1)
-                CGH_VEC_VAR(2)
                 CGH_VEC_VAR(3)
+                CGH_VEC_VAR(7)
+                CGH_VEC_VAR(11)
+                CGH_VEC_VAR(15)
+            default:
+                cgh_set_error("CGH_VEC_VARIANT=%d is not built (0,1,3,7,11,15)", vv);
+                return CGH_EINVAL;
             }
 #undef CGH_VEC_VAR
         }

@@ -1,4 +1,5 @@
 import ctypes as C, os
+import sys; sys.path.insert(0, ".")
 import conjugate_gradient_amd as cga
 cga.init(0)
 ms = C.c_double()

@@ -1,7 +1,7 @@
 """GPU measurement script: SpMV time per layout on the 256^3 7-point matrix, and CG rate at the foam sizes."""
 import ctypes as C, sys, time
 import numpy as np
-sys.path.insert(0, "tests")
+sys.path.insert(0, "tests"); sys.path.insert(0, ".")
 import conjugate_gradient_amd as cga
 import foamio
 cga.init(0)

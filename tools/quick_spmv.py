@@ -1,4 +1,5 @@
 """GPU tuning script: 256^3 7-point ELL SpMV / CG timing (env CGH_ELL_VARIANT selects a kernel variant)."""
+import sys; sys.path.insert(0, ".")
 import sys, os
 import ctypes as C
 import conjugate_gradient_amd as cga
