@@ -39,8 +39,21 @@ __device__ __forceinline__ double block_sum_256(double v, double *lds)
 // a launch derive bit-identical scalars from the same partials.
 __device__ __forceinline__ double block_sum_partials(const double *parts, int count, int stride, double *lds)
 {
+    // The loads are issued eight at a time before any is consumed (a plain strided loop serialises ~8 L2 round trips,
+    // which is most of the run time of the small kernels that call this); the additions keep the order k = tid,
+    // tid+256, ... so the result does not depend on the batching.
     double v = 0.0;
-    for (int k = threadIdx.x; k < count; k += 256) v += parts[(size_t)k * stride];
+    for (int base = threadIdx.x; base < count; base += 8 * 256) {
+        double t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int k = base + u * 256;
+            t[u] = k < count ? parts[(size_t)k * stride] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (base + u * 256 < count) v += t[u];
+    }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     v = wave_sum(v);
     if (lane == 0) lds[wave] = v;

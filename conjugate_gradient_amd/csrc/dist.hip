@@ -103,11 +103,11 @@ __global__ __launch_bounds__(256) void gather_rows(int64_t count, const int *__r
 template <int W>
 __global__ __launch_bounds__(CGH_BLOCK) void reduce_local(const double *__restrict__ partials, int count, double *__restrict__ out)
 {
+    // one workgroup per scalar (gridDim.x == W): the W sums run side by side instead of one after the other
     __shared__ double lds[4];
-    for (int w = 0; w < W; ++w) {
-        const double v = block_sum_partials(partials + w, count, W, lds);
-        if (threadIdx.x == 0) out[w] = v;
-    }
+    const int         w = blockIdx.x;
+    const double      v = block_sum_partials(partials + w, count, W, lds);
+    if (threadIdx.x == 0) out[w] = v;
 }
 
 __global__ void finish_init_dist(const double *__restrict__ gs, double *hist)
@@ -527,7 +527,7 @@ int cgh_dist_start(cgh_dist *d, const double *d_b, double *d_x, double tol, int 
     rc = spmv_ranges(d, true, true, false, &cnt, s, nullptr);  // Ap = A*0, as the reference computes it (cg.c:441)
     if (rc) return rc;
     hipLaunchKernelGGL(cg_init_rp, dim3(d->vgrid), dim3(CGH_BLOCK), 0, s, nl, d_b, (const double *)d->Ap, d->r, d->p, d->partB);
-    hipLaunchKernelGGL(reduce_local<2>, dim3(1), dim3(CGH_BLOCK), 0, s, (const double *)d->partB, d->vgrid, d->gs_local + 1);
+    hipLaunchKernelGGL(reduce_local<2>, dim3(2), dim3(CGH_BLOCK), 0, s, (const double *)d->partB, d->vgrid, d->gs_local + 1);
     CGH_HIP(hipGetLastError());
     CGH_NCCL(g_rccl.AllReduce(d->gs_local + 1, d->gs + 1, 2, ncclDouble, ncclSum, g_rccl.comm, s));
     hipLaunchKernelGGL(finish_init_dist, dim3(1), dim3(1), 0, s, (const double *)d->gs, d->hist);
@@ -572,7 +572,7 @@ int cgh_dist_iterate(cgh_dist *d, int count, int time_kernels)
         hipLaunchKernelGGL((cg_update_xr<2, 3>), dim3(d->vgrid), dim3(CGH_BLOCK), 0, s, nl, d->x, (const double *)d->p, d->r,
                            (const double *)d->Ap, (const double *)nullptr, 0, d->partB, d->hist, iter, (const int *)d->done, 0,
                            (const double *)d->gs);
-        hipLaunchKernelGGL(reduce_local<2>, dim3(1), dim3(CGH_BLOCK), 0, s, (const double *)d->partB, d->vgrid, d->gs_local + 1);
+        hipLaunchKernelGGL(reduce_local<2>, dim3(2), dim3(CGH_BLOCK), 0, s, (const double *)d->partB, d->vgrid, d->gs_local + 1);
         CGH_NCCL(g_rccl.AllReduce(d->gs_local + 1, d->gs + 1, 2, ncclDouble, ncclSum, g_rccl.comm, s));
         hipLaunchKernelGGL((cg_update_p<2, 3>), dim3(d->vgrid), dim3(CGH_BLOCK), 0, s, nl, (const double *)d->r, d->p,
                            (const double *)nullptr, 0, d->hist, iter, d->tol, d->done, 0, (const double *)d->gs);
@@ -682,7 +682,7 @@ int cgh_dist_group_start(cgh_dist **R, int G, const double *const *d_b, double *
         rc = spmv_ranges(d, true, true, false, &cnt, s, nullptr);
         if (rc) return rc;
         hipLaunchKernelGGL(cg_init_rp, dim3(d->vgrid), dim3(CGH_BLOCK), 0, s, d->n_loc, d_b[g], (const double *)d->Ap, d->r, d->p, d->partB);
-        hipLaunchKernelGGL(reduce_local<2>, dim3(1), dim3(CGH_BLOCK), 0, s, (const double *)d->partB, d->vgrid, d->gs_local + 1);
+        hipLaunchKernelGGL(reduce_local<2>, dim3(2), dim3(CGH_BLOCK), 0, s, (const double *)d->partB, d->vgrid, d->gs_local + 1);
     }
     hipLaunchKernelGGL(group_allreduce, dim3(1), dim3(64), 0, s, G, (double *const *)d0->d_locals, (double *const *)d0->d_outs, 1, 2);
     for (int g = 0; g < G; ++g) hipLaunchKernelGGL(finish_init_dist, dim3(1), dim3(1), 0, s, (const double *)R[g]->gs, R[g]->hist);
@@ -719,7 +719,7 @@ int cgh_dist_group_iterate(cgh_dist **R, int G, int count)
             hipLaunchKernelGGL((cg_update_xr<2, 3>), dim3(d->vgrid), dim3(CGH_BLOCK), 0, s, d->n_loc, d->x, (const double *)d->p, d->r,
                                (const double *)d->Ap, (const double *)nullptr, 0, d->partB, d->hist, iter, (const int *)d->done, 0,
                                (const double *)d->gs);
-            hipLaunchKernelGGL(reduce_local<2>, dim3(1), dim3(CGH_BLOCK), 0, s, (const double *)d->partB, d->vgrid, d->gs_local + 1);
+            hipLaunchKernelGGL(reduce_local<2>, dim3(2), dim3(CGH_BLOCK), 0, s, (const double *)d->partB, d->vgrid, d->gs_local + 1);
         }
         hipLaunchKernelGGL(group_allreduce, dim3(1), dim3(64), 0, s, G, (double *const *)d0->d_locals, (double *const *)d0->d_outs, 1, 2);
         for (int g = 0; g < G; ++g) {

@@ -179,3 +179,23 @@ def test_graph_replay_matches_eager(cga, strict, monkeypatch):
     rep2, hist2 = cga.cg_solve(A, b, x2, max_iter=1000, tol=1e-6, strict=strict, check_every=32)
     assert rep2.ret == rep.ret and same_bits_nan(hist2, hist)
     assert np.array_equal(bits(x2.to_host()), bits(x.to_host()))
+
+
+def test_foam128k_standin_strict_parity(cga):
+    """BASELINE configs 1-2 name foam_128k, whose file is a missing LFS blob in the reference checkout (SURVEY.md top).
+    Size stand-in: 2-D 5-point grid 400x320 = 128000 rows, K = 4 (the 7-point generator with nz = 1).  Strict-mode CG on
+    the GPU vs the oracle on the host: bit-identical trajectory and solution at that size."""
+    nx, ny = 400, 320
+    n = nx * ny
+    b = cga.DeviceVector(n); x = cga.DeviceVector(n)
+    A = cga.Matrix.poisson(nx, ny, 1, 7, 0x5EED0001, cga.LAYOUT_ELL, b)
+    assert (A.n, A.K) == (128000, 4)
+    ev, ec = A.download_ell(); diag = A.download_diag(); bh = b.to_host()
+    ret, xo, traj = O.cg(O.FMT_ELL_FULL, n, diag, 0, ev, ec, None, 4, bh, 1000, 1e-6)
+    rep, hist = cga.cg_solve(A, b, x, max_iter=1000, tol=1e-6, strict=1)
+    assert ret > 0 and rep.ret == ret
+    assert same_bits_nan(hist, traj) and np.array_equal(bits(x.to_host()), bits(xo))
+    rep2, hist2 = cga.cg_solve(A, b, x, max_iter=1000, tol=1e-6, strict=0)
+    assert abs(rep2.ret - ret) <= 1
+    m = min(hist2.shape[0], traj.shape[0])
+    assert (np.abs(hist2[:m, 0] - traj[:m, 0]) / traj[:m, 0]).max() < 1e-10
