@@ -171,7 +171,8 @@ void launch_r2(int K, int grid, hipStream_t s, int64_t n, const double *diag, co
         hipLaunchKernelGGL((spmv_ell_r2<KK, DOT, VAR>), dim3(grid), dim3(CGH_BLOCK), 0, s, n, K, diag, vals, cols, x, y, \
                            partials, done, g_cgh.sweep_reverse, rb, re, rb2, re2);                                                                    \
         break;
-    switch (K) {
+    static const int generic = getenv("CGH_ELL_GENERIC") ? atoi(getenv("CGH_ELL_GENERIC")) : 0;
+    switch (generic ? -1 : K) {
         CGH_ELL_CASE(1)
         CGH_ELL_CASE(2)
         CGH_ELL_CASE(3)
