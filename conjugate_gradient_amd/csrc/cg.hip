@@ -44,11 +44,35 @@ int vec_grid(int64_t n)
     return cgh_stream_grid((n + 2 * CGH_BLOCK - 1) / (2 * CGH_BLOCK), 8);
 }
 
+// Vectors of at least this many elements take the order-exact PARALLEL sums of xsum.hip in strict mode; shorter ones
+// the single-lane seq_sums kernel (same bits either way).  CGH_XSUM_MIN_ROWS overrides (0 = always, -1 = never).
+int64_t xsum_min_rows()
+{
+    const char *e = getenv("CGH_XSUM_MIN_ROWS");
+    const int64_t v = e ? atoll(e) : 16384;  // measured crossover on MI355X: ~225 us/iteration either way
+    return v < 0 ? INT64_MAX : v;
+}
+
+struct xsum_guard {
+    cgh_xsum *w = nullptr;
+    ~xsum_guard() { cgh_xsum_free(w); }
+};
+
 int reduce_pair(const double *a, const double *b, const double *c, int64_t n, int strict, double *h_out2)
 {
     scratch_buf parts(sizeof(double) * 2 * CGH_MAX_PARTIALS), out(sizeof(double) * 2);
     if (!parts.p || !out.p) return CGH_ENOMEM;
     hipStream_t s = g_cgh.stream;
+    xsum_guard  xg;
+    const uintptr_t al = reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(c);
+    if (strict && n >= xsum_min_rows() && !(al & 15u)) {
+        xg.w = cgh_xsum_create(n);
+        if (!xg.w) return CGH_ENOMEM;
+        CGH_HIP(hipMemsetAsync(out.p, 0, 2 * sizeof(double), s));
+        const int rc = cgh_xsum_launch(xg.w, n, a, b, c, 0, nullptr, 0, 0.0, nullptr, (double *)out.p, s);
+        if (rc) return rc;
+        return cgh_d2h(h_out2, out.p, 2 * sizeof(double));  // synchronises before the workspace is released
+    }
     if (strict) {
         hipLaunchKernelGGL(seq_sums, dim3(1), dim3(CGH_BLOCK), 0, s, n, a, b, c, 0, (double *)nullptr, 0, 0.0,
                            (int *)nullptr, (double *)out.p);
@@ -75,10 +99,20 @@ struct cgh_solver {
     double           *r = nullptr, *p = nullptr, *Ap = nullptr;
     double           *partA = nullptr, *partB = nullptr, *hist = nullptr;
     int              *done = nullptr;
+    cgh_xsum         *xs = nullptr;   // order-exact parallel sums (strict mode of long vectors), created on demand
     std::vector<hipEvent_t> kev;      // SpMV kernel brackets (time_kernels)
     // HIP graphs of `count` iterations (launch-bound sizes): kernels take the iteration number from the device
     std::vector<std::pair<int, hipGraphExec_t>> graphs;
 };
+
+// The strict-mode sums of the solver (modes: see seq_sums): parallel order-exact sums for long vectors, one lane otherwise.
+static int strict_sums(cgh_solver *sv, const double *a, const double *b, const double *c, int mode, int iter, hipStream_t s)
+{
+    if (sv->xs) return cgh_xsum_launch(sv->xs, sv->n, a, b, c, mode, sv->hist, iter, sv->tol, sv->done, nullptr, s);
+    hipLaunchKernelGGL(seq_sums, dim3(1), dim3(CGH_BLOCK), 0, s, sv->n, a, b, c, mode, sv->hist, iter, sv->tol, sv->done,
+                       (double *)nullptr);
+    return CGH_OK;
+}
 
 extern "C" {
 
@@ -155,6 +189,7 @@ void cgh_solver_free(cgh_solver *sv)
     cgh_free(sv->partB);
     cgh_free(sv->hist);
     cgh_free(sv->done);
+    cgh_xsum_free(sv->xs);
     delete sv;
 }
 
@@ -186,11 +221,16 @@ int cgh_solver_start(cgh_solver *sv, const double *d_b, double *d_x, double tol,
     if (rc) return rc;
     hipLaunchKernelGGL(cg_init_rp, dim3(sv->vgrid), dim3(CGH_BLOCK), 0, s, n, d_b, (const double *)sv->Ap, sv->r, sv->p,
                        sv->partB);
-    if (sv->strict)
-        hipLaunchKernelGGL(seq_sums, dim3(1), dim3(CGH_BLOCK), 0, s, n, (const double *)sv->r, (const double *)sv->r,
-                           (const double *)sv->r, 3, sv->hist, 0, tol, sv->done, (double *)nullptr);
-    else
+    if (sv->strict) {
+        if (!sv->xs && n >= xsum_min_rows()) {
+            sv->xs = cgh_xsum_create(n);
+            if (!sv->xs) return CGH_ENOMEM;
+        }
+        rc = strict_sums(sv, sv->r, sv->r, sv->r, 3, 0, s);
+        if (rc) return rc;
+    } else {
         hipLaunchKernelGGL(cg_finish_init, dim3(1), dim3(CGH_BLOCK), 0, s, (const double *)sv->partB, sv->vgrid, sv->hist);
+    }
     CGH_HIP(hipGetLastError());
     return CGH_OK;
 }
@@ -229,12 +269,12 @@ static int enqueue_iterations(cgh_solver *sv, int count, int time_kernels, bool 
         g_cgh.sweep_reverse = 0;
         if (time_kernels) CGH_HIP(hipEventRecord(sv->kev.back(), s));
         if (sv->strict) {
-            hipLaunchKernelGGL(seq_sums, dim3(1), dim3(CGH_BLOCK), 0, s, n, (const double *)dp, (const double *)dAp,
-                               (const double *)nullptr, 1, dh, iter, tol, dd, (double *)nullptr);
+            rc = strict_sums(sv, dp, dAp, nullptr, 1, iter, s);
+            if (rc) return rc;
             hipLaunchKernelGGL((cg_update_xr<1, 3>), dim3(vg), dim3(CGH_BLOCK), 0, s, n, d_x, (const double *)dp, dr,
                                (const double *)dAp, (const double *)dA, gridA, dB, dh, iter, (const int *)dd, rev2, (const double *)nullptr);
-            hipLaunchKernelGGL(seq_sums, dim3(1), dim3(CGH_BLOCK), 0, s, n, (const double *)dr, (const double *)dr,
-                               (const double *)dr, 2, dh, iter, tol, dd, (double *)nullptr);
+            rc = strict_sums(sv, dr, dr, dr, 2, iter, s);
+            if (rc) return rc;
             hipLaunchKernelGGL((cg_update_p<1, 3>), dim3(vg), dim3(CGH_BLOCK), 0, s, n, (const double *)dr, dp,
                                (const double *)dB, vg, dh, iter, tol, dd, rev1, (const double *)nullptr);
         } else {

@@ -7,7 +7,7 @@
 
 namespace {
 
-constexpr int HIST = 4;  // doubles per history entry: res, rr, alpha, beta
+constexpr int HIST = CGH_HIST;  // doubles per history entry: res, rr, alpha, beta
 
 typedef double d2_t __attribute__((ext_vector_type(2)));
 

@@ -74,6 +74,7 @@ struct cgh_matrix {
 // ------------------------------------------------------------ launch shapes
 constexpr int CGH_BLOCK = 256;          // 4 waves of 64
 constexpr int CGH_MAX_PARTIALS = 2048;  // upper bound on any reducing grid
+constexpr int CGH_HIST = 4;             // doubles per history entry of the CG driver: res, rr, alpha, beta
 
 // Number of blocks for a grid-stride streaming / reducing kernel over `tiles` tiles.
 static inline int cgh_stream_grid(int64_t tiles, int blocks_per_cu)
@@ -94,3 +95,13 @@ int cgh_spmv_grid(const cgh_matrix *m);
 // convert.hip
 cgh_matrix *cgh_matrix_from_entries_device(int64_t n, int64_t U, const double *d_diag, const double *d_upper,
                                            const int *d_rows, const int *d_cols, int layout);
+
+// xsum.hip -- order-exact parallel sums (the strict mode of large vectors)
+struct cgh_xsum;
+cgh_xsum *cgh_xsum_create(int64_t n);
+void      cgh_xsum_free(cgh_xsum *w);
+// Same contract as the seq_sums kernel (cg_kernels.h): dot = sum a[i]*b[i] (a != NULL), l1 = sum |c[i]| (c != NULL), both
+// added strictly left to right; mode 0: out = {dot, l1}; 1: alpha; 2: res, rr, beta, done; 3: initial res, rr.
+// a, b, c must either be (a, b, NULL), (NULL, NULL, c) or (v, v, v).
+int cgh_xsum_launch(cgh_xsum *w, int64_t n, const double *a, const double *b, const double *c, int mode, double *hist,
+                    int iter, double tol, int *done, double *out, hipStream_t s);

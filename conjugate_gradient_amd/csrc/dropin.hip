@@ -7,8 +7,9 @@
 // without touching their outputs.
 //
 // Environment: CG_HIP_DEVICE (default 0), CG_HIP_QUIET=1 (suppress the reference's printf chatter),
-// CG_HIP_MODE=strict|fast|auto (reduction order of the CG dots: strict = the reference's left-to-right
-// sums, bit-identical trajectory; fast = tree reductions; auto = strict up to 262144 rows, default).
+// CG_HIP_MODE=strict|fast (reduction order of the CG dots: strict = the reference's left-to-right sums,
+// bit-identical trajectory, the default at every size -- one lane below 16384 rows, the order-exact parallel
+// sums of xsum.hip above; fast = tree reductions, ~2.4x faster per iteration at 16.7M rows).
 #include <cmath>
 #include <vector>
 
@@ -38,9 +39,9 @@ bool ensure_ready()
 int strict_for(int64_t n)
 {
     const char *m = getenv("CG_HIP_MODE");
-    if (m && !strcmp(m, "strict")) return 1;
+    (void)n;
     if (m && !strcmp(m, "fast")) return 0;
-    return n <= 262144;
+    return 1;
 }
 
 template <typename T>

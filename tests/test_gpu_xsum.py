@@ -1,0 +1,115 @@
+"""Order-exact parallel sums on the device (csrc/xsum.hip) against the reference's left-to-right vec_dot / vec_l1norm
+(/root/reference/src/vec.c:67-85, restated in oracle/cg_oracle.c): bit-identical on every input, and the strict CG
+trajectory built on them bit-identical to the reference loop at BASELINE's full size (256^3)."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from gpu_common import bits, golden, inputs, same_bits_nan
+from test_xsum_model import cases
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def cga():
+    import conjugate_gradient_amd as m
+    m.init(0)
+    return m
+
+
+def seq_sum(t):
+    one = np.ones_like(t)
+    return O.lib().orc_vec_dot(O.D(np.ascontiguousarray(t)), O.D(one), t.size)
+
+
+def eq(a, b):
+    return (np.isnan(a) and np.isnan(b)) or np.float64(a).view(np.uint64) == np.float64(b).view(np.uint64)
+
+
+@pytest.mark.parametrize("name,t", [c for c in cases() if c[1].size > 0], ids=[c[0] for c in cases() if c[1].size > 0])
+def test_device_sum_equals_sequential(cga, monkeypatch, name, t):
+    """sum t[i] as dot(t, 1) and, for non-negative data, as l1norm(t): forced through the parallel path at every size"""
+    monkeypatch.setenv("CGH_XSUM_MIN_ROWS", "0")
+    t = np.ascontiguousarray(t, dtype=np.float64)
+    n = t.size
+    dt = cga.DeviceVector.from_host(t); d1 = cga.DeviceVector.from_host(np.ones(n))
+    v = np.zeros(1)
+    cga.binding.check(cga.lib().cgh_dot(dt.ptr, d1.ptr, n, 1, O.D(v)))
+    assert eq(v[0], seq_sum(t)), (name, v[0], seq_sum(t))
+    cga.binding.check(cga.lib().cgh_l1norm(dt.ptr, n, 1, O.D(v)))
+    want = O.lib().orc_vec_l1norm(O.D(t), n)
+    assert eq(v[0], want), (name, v[0], want)
+
+
+def test_device_dot_products(cga, monkeypatch):
+    rng = np.random.default_rng(5)
+    for n in (70000, 1 << 20, (1 << 22) + 77):
+        a = rng.standard_normal(n); b = a * (1.0 + 0.1 * rng.standard_normal(n))
+        da = cga.DeviceVector.from_host(a); db = cga.DeviceVector.from_host(b)
+        v = np.zeros(1)
+        cga.binding.check(cga.lib().cgh_dot(da.ptr, db.ptr, n, 1, O.D(v)))
+        assert eq(v[0], O.lib().orc_vec_dot(O.D(a), O.D(b), n))
+        cga.binding.check(cga.lib().cgh_dot(da.ptr, da.ptr, n, 1, O.D(v)))
+        assert eq(v[0], O.lib().orc_vec_dot(O.D(a), O.D(a), n))
+        cga.binding.check(cga.lib().cgh_l1norm(db.ptr, n, 1, O.D(v)))
+        assert eq(v[0], O.lib().orc_vec_l1norm(O.D(b), n))
+
+
+@pytest.mark.parametrize("tag", ["cylinder_2000", "cylinder_32k", "poisson27_12x10x8"])
+def test_strict_cg_through_parallel_sums(cga, monkeypatch, tag):
+    """the golden trajectories again, with every strict sum forced through xsum.hip instead of the one-lane kernel"""
+    monkeypatch.setenv("CGH_XSUM_MIN_ROWS", "0")
+    s, g = inputs(tag), golden(tag)
+    n, K = s["n"], int(g["K_full"])
+    A = cga.Matrix.from_ell(n, K, s["diag"], g["ell_full_vals"], g["ell_full_cols"])
+    b = cga.DeviceVector.from_host(s["source"]); x = cga.DeviceVector(n)
+    rep, hist = cga.cg_solve(A, b, x, max_iter=int(g["max_iter"]), tol=float(g["tol"]), strict=1, check_every=64)
+    assert rep.ret == int(g["cg_ret"][4])
+    assert same_bits_nan(hist, g["traj"])
+    assert np.array_equal(bits(x.to_host()), bits(g["cg_x"]))
+
+
+def test_full_size_256cubed_strict_bit_exact(cga):
+    """BASELINE config 3 at full size: strict mode (parallel order-exact sums) against the reference's own arithmetic
+    on the host (oracle/_ref/libref.so when present, else the oracle port): (res, rr, alpha, beta) and x bit-identical."""
+    import ctypes as C
+    import os
+    N, iters = 256, 6
+    n = N ** 3
+    b = cga.DeviceVector(n); x = cga.DeviceVector(n)
+    A = cga.Matrix.poisson(N, N, N, 7, 0x5EED0001, cga.LAYOUT_ELL, b)
+    ev, ec = A.download_ell(); diag = A.download_diag(); bh = b.to_host()
+    K = A.K
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    ref_so = os.path.join(root, "oracle", "_ref", "libref.so")
+    if os.path.exists(ref_so):
+        R = C.CDLL(ref_so)
+        R.vec_dot.restype = C.c_double; R.vec_l1norm.restype = C.c_double
+        R.vec_axpy.argtypes = [O.dp, O.dp, C.c_double, O.dp, C.c_int]
+        mv = lambda v, out: R.mv_ell_symmetric_full_colmajor(n, K, O.D(diag), O.D(ev), O.I(ec), O.D(v), O.D(out))
+        dot = lambda u, v: R.vec_dot(O.D(u), O.D(v), n)
+        l1 = lambda u: R.vec_l1norm(O.D(u), n)
+        axpy = lambda a_, b_, al, out: R.vec_axpy(O.D(a_), O.D(b_), al, O.D(out), n)
+    else:
+        L = O.lib()
+        mv = lambda v, out: L.orc_mv_ell_symmetric_full_colmajor(n, K, O.D(diag), O.D(ev), O.I(ec), O.D(v), O.D(out))
+        dot = lambda u, v: L.orc_vec_dot(O.D(u), O.D(v), n)
+        l1 = lambda u: L.orc_vec_l1norm(O.D(u), n)
+        axpy = lambda a_, b_, al, out: L.orc_vec_axpy(O.D(a_), O.D(b_), al, O.D(out), n)
+    xr = np.zeros(n); r = bh.copy(); p = bh.copy(); Ap = np.empty(n)
+    rr = dot(r, r)
+    want = [[l1(r) / 2.0, rr, np.nan, np.nan]]
+    for _ in range(iters):
+        mv(p, Ap)
+        alpha = rr / dot(p, Ap)
+        axpy(xr, p, alpha, xr); axpy(r, Ap, -alpha, r)
+        rr_new = dot(r, r)
+        beta = rr_new / rr
+        want.append([l1(r) / 2.0, rr_new, alpha, beta])
+        axpy(r, p, beta, p)
+        rr = rr_new
+    rep, hist = cga.cg_solve(A, b, x, fixed_iters=iters, strict=1)
+    print("\n[256^3 strict] %d iterations in %.2f ms = %.3f ms/iteration" % (iters, rep.solve_ms, rep.solve_ms / iters))
+    assert same_bits_nan(hist, np.array(want))
+    assert np.array_equal(bits(x.to_host()), bits(xr))
