@@ -4,7 +4,8 @@
 //
 // Four launches per call, for one or two sums over the same index range (slot 0 = dot, slot 1 = l1):
 //   xs_cell_sums   one workgroup per group (64 cells x 128 elements): approximate (tree) sum of every cell and group
-//   xs_group_scan  one workgroup: exclusive prefix of the group sums
+//   xs_group_scan  one workgroup: exclusive prefix of the group sums (only beyond 4096 groups; below that every
+//                  workgroup of xs_summarize adds up the sums of the groups before it)
 //   xs_summarize   one workgroup per group: predicted running sum at each cell start -> assumed binade ->
 //                  integer summary {D, lo, hi} of every cell, and their join per group
 //   xs_drive       one wave per sum: walks the group summaries 64 at a time (one per lane, validated and applied
@@ -137,17 +138,43 @@ __device__ __forceinline__ xs_summary wave_join(xs_summary q)
     return q;
 }
 
+// terms of the 8 consecutive elements i .. i+7 (i a multiple of 8) for the slots in use
+template <int KIND>
+__device__ __forceinline__ void xs_terms8(int64_t n, const double *__restrict__ a, const double *__restrict__ b,
+                                          const double *__restrict__ c, int64_t i, double (&t)[2][8])
+{
+#pragma unroll
+    for (int k = 0; k < 8; k += 2) {
+        double d[2], l[2];
+        xs_terms<KIND>(n, a, b, c, i + k, d, l);
+        t[0][k] = d[0];
+        t[0][k + 1] = d[1];
+        t[1][k] = l[0];
+        t[1][k + 1] = l[1];
+    }
+}
+
+// One workgroup per group.  16 lanes share a cell (8 consecutive elements each: a short serial prefix in registers,
+// then a 4-step tree inside the 16 lanes), so a wave summarises 4 cells at a time and the workgroup 16.  Inside a
+// cell no saturation is needed: 128 elements of |d| < 2^52 stay below 2^59.
 template <int KIND>
 __global__ __launch_bounds__(256) void xs_summarize(int64_t n, const double *__restrict__ a, const double *__restrict__ b,
                                                    const double *__restrict__ c, int64_t ncells, int64_t ngroups,
-                                                   const double *__restrict__ cellsum, const double *__restrict__ gprefix,
-                                                   xs_summary *__restrict__ cells, xs_summary *__restrict__ groups)
+                                                   const double *__restrict__ cellsum, const double *__restrict__ groupsum,
+                                                   const double *__restrict__ gprefix, xs_summary *__restrict__ cells,
+                                                   xs_summary *__restrict__ groups)
 {
     constexpr int S0 = KIND == XS_L1 ? 1 : 0, S1 = KIND == XS_DOT ? 0 : 1;  // slots in use: S0..S1
     __shared__ double     start[2][XS_GROUP];  // predicted running sum at the start of each cell
     __shared__ xs_summary sm[2][XS_GROUP];
+    __shared__ double     red[4];
     const int     lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t g = blockIdx.x;
+    // approximate sum of everything before this group: from the scan kernel, or (few groups) summed here
+    double before[2] = {0.0, 0.0};
+#pragma unroll
+    for (int slot = S0; slot <= S1; ++slot)
+        before[slot] = gprefix ? gprefix[slot * ngroups + g] : block_sum_partials(groupsum + slot * ngroups, (int)g, 1, red);
     if (wave >= S0 && wave <= S1) {
         const int64_t cell = g * XS_GROUP + lane;
         const double  v = cell < ncells ? cellsum[wave * ncells + cell] : 0.0;
@@ -157,51 +184,51 @@ __global__ __launch_bounds__(256) void xs_summarize(int64_t n, const double *__r
             const double o = __shfl_up(incl, off, 64);
             if (lane >= off) incl += o;
         }
-        start[wave][lane] = gprefix[wave * ngroups + g] + (incl - v);
+        start[wave][lane] = (wave ? before[1] : before[0]) + (incl - v);
     }
     __syncthreads();
-#pragma unroll 2
-    for (int cc = 0; cc < 16; ++cc) {
-        const int     ci = wave * 16 + cc;
+    const int sub = threadIdx.x & 15;  // position inside the cell's 16 lanes
+#pragma unroll 1
+    for (int pass = 0; pass < 4; ++pass) {
+        const int     ci = pass * 16 + (threadIdx.x >> 4);
         const int64_t cell = g * XS_GROUP + ci;
-        double        t[2][2];
-        xs_terms<KIND>(cell < ncells ? n : 0, a, b, c, cell * XS_CELL + 2 * lane, t[0], t[1]);
+        double        t[2][8];
+        xs_terms8<KIND>(cell < ncells ? n : 0, a, b, c, cell * XS_CELL + 8 * sub, t);
 #pragma unroll
         for (int slot = S0; slot <= S1; ++slot) {
-            xs_summary q = xs_identity();
-            if (cell < ncells) {
-                int32_t E, neg;
-                if (xs_binade_of(start[slot][ci], &E, &neg)) {
-                    bool          bad0 = false, bad1 = false;
-                    const int64_t d0 = xs_element(t[slot][0], E, neg, &bad0), d1 = xs_element(t[slot][1], E, neg, &bad1);
-                    int64_t       D = d0 + d1;  // |d| < 2^52 each
-                    int64_t       lo = d0 < 0 ? d0 : 0, hi = d0 > 0 ? d0 : 0;
-                    lo = D < lo ? D : lo;
-                    hi = D > hi ? D : hi;
-                    // all lanes assume the same binade: only D / lo / hi travel through the tree
+            int32_t    E, neg;
+            const bool usable = xs_binade_of(start[slot][ci], &E, &neg);  // else: predicted 0 / subnormal / non-finite
+            bool       bad = !usable;
+            int64_t    D = 0, lo = 0, hi = 0;
 #pragma unroll
-                    for (int off = 1; off < 64; off <<= 1) {
-                        const int64_t oD = shfl_down_i64(D, off), olo = shfl_down_i64(lo, off), ohi = shfl_down_i64(hi, off);
-                        if (lane + off < 64) {
-                            const int64_t blo = xs_sat_add(D, olo), bhi = xs_sat_add(D, ohi);
-                            lo = lo < blo ? lo : blo;
-                            hi = hi > bhi ? hi : bhi;
-                            D = xs_sat_add(D, oD);
-                        }
-                    }
-                    const bool any_bad = __ballot(bad0 || bad1) != 0ull;
+            for (int k = 0; k < 8; ++k) {
+                const int64_t d = xs_element(t[slot][k], usable ? E : 1075, neg, &bad);
+                D += d;
+                lo = D < lo ? D : lo;
+                hi = D > hi ? D : hi;
+            }
+#pragma unroll
+            for (int off = 1; off < 16; off <<= 1) {
+                const int64_t oD = shfl_down_i64(D, off), olo = shfl_down_i64(lo, off), ohi = shfl_down_i64(hi, off);
+                if (sub + off < 16) {
+                    const int64_t blo = D + olo, bhi = D + ohi;
+                    lo = lo < blo ? lo : blo;
+                    hi = hi > bhi ? hi : bhi;
+                    D += oD;
+                }
+            }
+            const unsigned long long bad_lanes = __ballot(bad);
+            if (sub == 0) {
+                xs_summary q = xs_identity();
+                if (cell < ncells) {
                     q.D = D;
                     q.lo = lo;
                     q.hi = hi;
-                    q.E = E;
-                    q.meta = (neg ? 2 : 0) | (any_bad ? XS_IRREGULAR : 0);
-                } else {
-                    q.meta = XS_IRREGULAR;  // running sum predicted 0 / subnormal / non-finite: element by element
+                    q.E = usable ? E : 0;
+                    q.meta = (neg ? 2 : 0) | (((bad_lanes >> (lane & 48)) & 0xffffull) ? XS_IRREGULAR : 0);
+                    cells[slot * ncells + cell] = q;
                 }
-            }
-            if (lane == 0) {
                 sm[slot][ci] = q;
-                if (cell < ncells) cells[slot * ncells + cell] = q;
             }
         }
     }
@@ -219,6 +246,21 @@ __device__ __forceinline__ double readlane_f64(double v, int k)
     return __hiloint2double(hi, lo);
 }
 
+// v of the lane selected by a DPP control (0 where the control has no source lane or the row is masked out)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int64_t dpp_i64(int64_t v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)v, CTRL, ROW_MASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(v >> 32), CTRL, ROW_MASK, 0xf, false);
+    return (int64_t)(((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo);
+}
+
+__device__ __forceinline__ int64_t readlane_i64(int64_t v, int k)
+{
+    const int lo = __builtin_amdgcn_readlane((int)(uint32_t)v, k), hi = __builtin_amdgcn_readlane((int)(v >> 32), k);
+    return (int64_t)(((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo);
+}
+
 // Items [start, cnt) of a batch (one summary per lane): apply the longest valid prefix to the running sum s
 // (wave-uniform) and return the index of the first item that does not apply (cnt if all did).
 __device__ __forceinline__ int xs_batch(const xs_summary &q, int start, int cnt, double &s)
@@ -234,34 +276,99 @@ __device__ __forceinline__ int xs_batch(const xs_summary &q, int start, int cnt,
     const int64_t M = xs_mantissa(s);
     const bool    active = lane >= start && lane < cnt;
     const int64_t D = active ? q.D : 0;
-    int64_t       incl = D;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const int64_t o = shfl_up_i64(incl, off);
-        if (lane >= off) incl = xs_sat_add(incl, o);
-    }
-    int64_t excl = shfl_up_i64(incl, 1);
-    if (lane == 0) excl = 0;
+    // Inclusive prefix over the lanes with DPP moves (no LDS crossbar round trips on this serial path).  Plain wrapping
+    // adds: the prefix of lane k involves lanes <= k only, so it is exact for every lane up to and including the first
+    // one that fails (all runs before it are valid, hence small), and nothing beyond that lane is used.
+    int64_t incl = D;
+    incl += dpp_i64<0x111, 0xf>(incl);  // row_shr:1
+    incl += dpp_i64<0x112, 0xf>(incl);  // row_shr:2
+    incl += dpp_i64<0x114, 0xf>(incl);  // row_shr:4
+    incl += dpp_i64<0x118, 0xf>(incl);  // row_shr:8   -> prefix inside each row of 16 lanes
+    incl += dpp_i64<0x142, 0xa>(incl);  // row_bcast:15 into rows 1 and 3
+    incl += dpp_i64<0x143, 0xc>(incl);  // row_bcast:31 into rows 2 and 3
+    const int64_t excl = incl - D;
     const bool               ok = !active || xs_applies(q, E0, neg0, xs_sat_add(M, excl));
     const unsigned long long fail = __ballot(!ok);
     const int                f = fail ? (int)__builtin_ctzll(fail) : cnt;
-    if (f > start) s = xs_compose(E0, neg0, M + shfl_i64(incl, f - 1));
+    if (f > start) s = xs_compose(E0, neg0, M + readlane_i64(incl, f - 1));
     return f;
 }
 
-// s + (the 128 elements of one cell), left to right.  Every lane carries the same s.
-template <int KIND>
-__device__ __forceinline__ double xs_cell_sequential(double s, int slot, int64_t n, const double *__restrict__ a,
-                                                     const double *__restrict__ b, const double *__restrict__ c, int64_t cell)
+// s + (the 128 elements of one cell: lane l holds elements 2l, 2l+1 in t0, t1), left to right.  Every lane carries the
+// same s.  The elements go through this wave's 1 KiB of LDS: the reads are broadcasts that do not depend on the
+// additions, so they run ahead of the one dependent chain (as chain_add of seq_sums, cg_kernels.h).
+__device__ __forceinline__ double xs_chain(double s, double t0, double t1, double *stage)
 {
     const int lane = threadIdx.x & 63;
-    double    t[2][2];
-    xs_terms<KIND>(n, a, b, c, cell * XS_CELL + 2 * lane, t[0], t[1]);
-    const double t0 = slot ? t[1][0] : t[0][0], t1 = slot ? t[1][1] : t[0][1];
-#pragma unroll 8
-    for (int k = 0; k < 64; ++k) {
-        s = add_rn(s, readlane_f64(t0, k));
-        s = add_rn(s, readlane_f64(t1, k));
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();  // the previous cell's reads are over
+    *reinterpret_cast<double2 *>(stage + 2 * lane) = make_double2(t0, t1);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll 2
+    for (int j = 0; j < XS_CELL; j += 16) {
+        double t[16];
+#pragma unroll
+        for (int k = 0; k < 16; k += 2) {
+            const double2 w = *reinterpret_cast<const double2 *>(stage + j + k);
+            t[k] = w.x;
+            t[k + 1] = w.y;
+        }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) s = add_rn(s, t[k]);
+    }
+    return s;
+}
+
+template <int KIND>
+__device__ __forceinline__ void xs_cell_terms(int slot, int64_t n, const double *__restrict__ a, const double *__restrict__ b,
+                                              const double *__restrict__ c, int64_t cell, double &t0, double &t1)
+{
+    double t[2][2];
+    xs_terms<KIND>(n, a, b, c, cell * XS_CELL + 2 * (threadIdx.x & 63), t[0], t[1]);
+    t0 = slot ? t[1][0] : t[0][0];
+    t1 = slot ? t[1][1] : t[0][1];
+}
+
+constexpr int XS_PF_CELLS = 6;  // cells of a group whose elements are fetched ahead (those flagged irregular)
+
+// The cells [c0, c0+ccnt) of one group (summary of cell c0+lane in C), applied to s.  The serial chain here is
+// memory latency, so the elements of the cells that are KNOWN to need the element-by-element path (irregular flag:
+// tie, binade change, ...) are requested up front, all at once; a cell that fails only the range check against the
+// actual running sum is fetched when it is met.
+template <int KIND>
+__device__ __forceinline__ double xs_walk_cells(double s, int slot, int64_t n, const double *__restrict__ a,
+                                                const double *__restrict__ b, const double *__restrict__ c, int64_t c0,
+                                                int ccnt, const xs_summary &C, double *stage)
+{
+    const int          lane = threadIdx.x & 63;
+    unsigned long long flagged = __ballot(lane < ccnt && (C.meta & XS_IRREGULAR));
+    int                pf_idx[XS_PF_CELLS];
+    double             pf_t0[XS_PF_CELLS], pf_t1[XS_PF_CELLS];
+#pragma unroll
+    for (int j = 0; j < XS_PF_CELLS; ++j) {
+        pf_idx[j] = flagged ? (int)__builtin_ctzll(flagged) : -1;
+        flagged &= flagged - 1;
+        pf_t0[j] = pf_t1[j] = 0.0;
+        if (pf_idx[j] >= 0) xs_cell_terms<KIND>(slot, n, a, b, c, c0 + pf_idx[j], pf_t0[j], pf_t1[j]);
+    }
+    int cstart = 0;
+    while (cstart < ccnt) {
+        const int cf = xs_batch(C, cstart, ccnt, s);
+        if (cf >= ccnt) break;
+        double t0 = 0.0, t1 = 0.0;
+        bool   have = false;
+#pragma unroll
+        for (int j = 0; j < XS_PF_CELLS; ++j)
+            if (pf_idx[j] == cf) {
+                t0 = pf_t0[j];
+                t1 = pf_t1[j];
+                have = true;
+            }
+        if (!have) xs_cell_terms<KIND>(slot, n, a, b, c, c0 + cf, t0, t1);
+        s = xs_chain(s, t0, t1, stage);
+        cstart = cf + 1;
     }
     return s;
 }
@@ -269,16 +376,30 @@ __device__ __forceinline__ double xs_cell_sequential(double s, int slot, int64_t
 template <int KIND>
 __device__ double xs_walk(int slot, int64_t n, const double *__restrict__ a, const double *__restrict__ b,
                           const double *__restrict__ c, int64_t ncells, int64_t ngroups, const xs_summary *__restrict__ cells,
-                          const xs_summary *__restrict__ groups)
+                          const xs_summary *__restrict__ groups, double *stage)
 {
     const int lane = threadIdx.x & 63;
     cells += slot * ncells;
     groups += slot * ngroups;
-    double s = 0.0;
+    double     s = 0.0;
+    xs_summary Qnext = xs_identity();
+    if (lane < ngroups) Qnext = groups[lane];
     for (int64_t g0 = 0; g0 < ngroups; g0 += 64) {
-        const int  cnt = (int)(ngroups - g0 < 64 ? ngroups - g0 : 64);
-        xs_summary Q = xs_identity();
-        if (lane < cnt) Q = groups[g0 + lane];
+        const int        cnt = (int)(ngroups - g0 < 64 ? ngroups - g0 : 64);
+        const xs_summary Q = Qnext;
+        Qnext = xs_identity();
+        if (g0 + 64 + lane < ngroups) Qnext = groups[g0 + 64 + lane];  // in flight while this batch is walked
+        // cell summaries of the first two groups already known to need their cells
+        unsigned long long flagged = __ballot(lane < cnt && (Q.meta & XS_IRREGULAR));
+        int                pf_g[2];
+        xs_summary         pf_C[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            pf_g[j] = flagged ? (int)__builtin_ctzll(flagged) : -1;
+            flagged &= flagged - 1;
+            pf_C[j] = xs_identity();
+            if (pf_g[j] >= 0 && (g0 + pf_g[j]) * XS_GROUP + lane < ncells) pf_C[j] = cells[(g0 + pf_g[j]) * XS_GROUP + lane];
+        }
         int start = 0;
         while (start < cnt) {
             const int f = xs_batch(Q, start, cnt, s);
@@ -286,14 +407,14 @@ __device__ double xs_walk(int slot, int64_t n, const double *__restrict__ a, con
             const int64_t c0 = (g0 + f) * XS_GROUP;
             const int     ccnt = (int)(ncells - c0 < XS_GROUP ? ncells - c0 : XS_GROUP);
             xs_summary    C = xs_identity();
-            if (lane < ccnt) C = cells[c0 + lane];
-            int cstart = 0;
-            while (cstart < ccnt) {
-                const int cf = xs_batch(C, cstart, ccnt, s);
-                if (cf >= ccnt) break;
-                s = xs_cell_sequential<KIND>(s, slot, n, a, b, c, c0 + cf);
-                cstart = cf + 1;
+            if (f == pf_g[0]) {
+                C = pf_C[0];
+            } else if (f == pf_g[1]) {
+                C = pf_C[1];
+            } else if (lane < ccnt) {
+                C = cells[c0 + lane];
             }
+            s = xs_walk_cells<KIND>(s, slot, n, a, b, c, c0, ccnt, C, stage);
             start = f + 1;
         }
     }
@@ -308,12 +429,13 @@ __global__ __launch_bounds__(128) void xs_drive(int64_t n, const double *__restr
 {
     constexpr int S0 = KIND == XS_L1 ? 1 : 0, S1 = KIND == XS_DOT ? 0 : 1;
     __shared__ double res[2];
+    __shared__ __attribute__((aligned(16))) double stage[2][XS_CELL];
     const int wave = threadIdx.x >> 6;
     if (threadIdx.x < 2) res[threadIdx.x] = 0.0;
     __syncthreads();
     const bool frozen = done != nullptr && mode != 3 && mode != 0 && *done != 0;
     if (!frozen && wave >= S0 && wave <= S1) {
-        const double s = xs_walk<KIND>(wave, n, a, b, c, ncells, ngroups, cells, groups);
+        const double s = xs_walk<KIND>(wave, n, a, b, c, ncells, ngroups, cells, groups, stage[wave]);
         if ((threadIdx.x & 63) == 0) res[wave] = s;
     }
     __syncthreads();
@@ -347,9 +469,14 @@ int launch_all(cgh_xsum *w, int64_t n, const double *a, const double *b, const d
 {
     const unsigned ng = (unsigned)w->ngroups;
     hipLaunchKernelGGL((xs_cell_sums<KIND>), dim3(ng), dim3(256), 0, s, n, a, b, c, w->ncells, w->ngroups, w->cellsum, w->groupsum);
-    hipLaunchKernelGGL(xs_group_scan, dim3(1), dim3(256), 0, s, w->ngroups, (const double *)w->groupsum, w->gprefix);
+    // few groups: every workgroup of xs_summarize adds the group sums before it itself (one launch less)
+    const double *prefix = nullptr;
+    if (w->ngroups > 4096) {
+        hipLaunchKernelGGL(xs_group_scan, dim3(1), dim3(256), 0, s, w->ngroups, (const double *)w->groupsum, w->gprefix);
+        prefix = w->gprefix;
+    }
     hipLaunchKernelGGL((xs_summarize<KIND>), dim3(ng), dim3(256), 0, s, n, a, b, c, w->ncells, w->ngroups,
-                       (const double *)w->cellsum, (const double *)w->gprefix, w->cells, w->groups);
+                       (const double *)w->cellsum, (const double *)w->groupsum, prefix, w->cells, w->groups);
     hipLaunchKernelGGL((xs_drive<KIND>), dim3(1), dim3(128), 0, s, n, a, b, c, w->ncells, w->ngroups,
                        (const xs_summary *)w->cells, (const xs_summary *)w->groups, mode, hist, iter, tol, done, out);
     CGH_HIP(hipGetLastError());
