@@ -174,8 +174,31 @@ def main():
     if os.path.exists(tpath):
         with open(tpath) as f:
             out["roofline"]["traffic"] = json.load(f)["hbm_bytes_per_launch"]
+    sv.free()
+    # attainable ceiling next to the spec peak: device-to-device copy of 1 GiB, bytes read + written
+    cbytes = min(1 << 30, (8 * n) // 16 * 16)
+    src = cga.DeviceVector(cbytes // 8)
+    dst = cga.DeviceVector(cbytes // 8)
+    ms = C.c_double(0.0)
+    cga.check(cga.lib().cgh_time_copy(dst.ptr, src.ptr, cbytes, 10, C.byref(ms)))
+    out["roofline"]["copy_ceiling_GBs"] = 2 * cbytes / (ms.value * 1e-3) / 1e9
+    out["roofline"]["frac_of_copy_ceiling"] = achieved / out["roofline"]["copy_ceiling_GBs"]
+    del src, dst
+    # the same loop in the parity mode (strict=1: the reference's left-to-right dot / L1 order, bit-identical
+    # trajectory, order-exact parallel sums of xsum.hip) -- reported beside the headline, never as `value`
+    ps = min(args.steps, 50)
+    sv = cga.Solver(A, ps + 3)
+    sv.start(b, x, tol=-1.0, strict=1)
+    sv.iterate(2, 0)
+    cga.check(cga.lib().cgh_sync())
+    t0 = time.perf_counter()
+    sv.iterate(ps, 0)
+    cga.check(cga.lib().cgh_sync())
+    pdt = time.perf_counter() - t0
+    sv.free()
+    out["parity_mode"] = {"value": ps / pdt, "unit": "iterations/s", "ms_per_step": pdt / ps * 1e3, "steps": ps,
+                          "note": "strict=1: dots and L1 norm in the reference's summation order (bit-identical trajectory)"}
     if not args.no_cpu_baseline:
-        sv.free()
         out["cpu_baseline"] = cpu_baseline(A, b)
     print(json.dumps(out), flush=True)
 

@@ -69,6 +69,7 @@ struct cgh_matrix {
     int     *bin_rows = nullptr; // [n] row ids grouped by bin
     int64_t  bin_start[5] = {0, 0, 0, 0, 0}; // short / sub-wave / wave / block rows
     bool     owns = true;
+    bool     exact_rows = false;  // CSR: add every row's products strictly left to right, however long the row is
 };
 
 // ------------------------------------------------------------ launch shapes

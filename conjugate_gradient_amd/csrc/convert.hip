@@ -574,6 +574,13 @@ int cgh_csr_to_ell_download(const cgh_matrix *m, double *ell_vals, int *ell_cols
 extern "C" {
 
 // Shortest row (stored off-diagonals) of a CSR-layout matrix; -1 for other layouts.
+int cgh_matrix_set_exact_rows(cgh_matrix *m, int exact)
+{
+    if (!m) return CGH_EINVAL;
+    m->exact_rows = exact != 0;
+    return CGH_OK;
+}
+
 int cgh_matrix_min_row(const cgh_matrix *m)
 {
     CGH_REQUIRE_READY(-1);

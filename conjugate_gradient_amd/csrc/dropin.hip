@@ -280,6 +280,7 @@ int conjugate_gradient_csr(const int n, double *diag, int upper_count, double *u
     hipLaunchKernelGGL(expand_row_ptr, dim3(grid_for(n)), dim3(256), 0, g_cgh.stream, (int64_t)n, (const int *)drp.p, dr.p);
     mat_guard g{cgh_matrix_from_coo_device(n, U, dd.p, dv.p, dr.p, dc.p, CGH_LAYOUT_CSR)};
     if (!g.m) return -1;
+    g.m->exact_rows = true;  // the reference's order in every row, whatever its length
     return run_cg("CG (CSR) \n\n", g.m, b, x, max_iter, tol);
 }
 
@@ -523,7 +524,9 @@ void mv_csr_symmetric(int n, const double *diag, const double *upper, const int 
     if (!dd.ok() || !dv.ok() || !drp.ok() || !dc.ok() || !dr.ok()) return;
     hipLaunchKernelGGL(expand_row_ptr, dim3(grid_for(n)), dim3(256), 0, g_cgh.stream, (int64_t)n, (const int *)drp.p, dr.p);
     mat_guard g{cgh_matrix_from_coo_device(n, U, dd.p, dv.p, dr.p, dc.p, CGH_LAYOUT_CSR)};
-    if (g.m) spmv_host(g.m, v, out);
+    if (!g.m) return;
+    g.m->exact_rows = true;
+    spmv_host(g.m, v, out);
 }
 
 // ------------------------------------------------------------------------------- include/coo.h
@@ -533,7 +536,9 @@ void mv_coo_symmetric(int n, int coo_length, const double *diag, const double *v
 {
     if (!ensure_ready()) return;
     mat_guard g{cgh_matrix_from_coo_host(n, coo_length, diag, value, rows, columns, CGH_LAYOUT_CSR)};
-    if (g.m) spmv_host(g.m, v, out);
+    if (!g.m) return;
+    g.m->exact_rows = true;
+    spmv_host(g.m, v, out);
 }
 
 // ------------------------------------------------------------------------------- include/vec.h

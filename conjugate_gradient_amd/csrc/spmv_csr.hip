@@ -13,7 +13,8 @@
 // with coalesced non-temporal loads, forms the rounded products v*x[col] into LDS, then
 //   * rows of <= 64 entries: one lane adds the row's products left to right (bit-exact order);
 //   * longer rows: a wave adds strided partial sums and combines them with a shuffle tree (NOT the
-//     reference's order; differs in the last bits.  CGH_CSR_EXACT=1 forces the exact path for all rows);
+//     reference's order; differs in the last bits.  cgh_matrix_set_exact_rows() / CGH_CSR_EXACT=1 force the exact path for all rows,
+//     which is what the reference-signature entry points of dropin.hip do);
 //   * a row longer than the window is a block of its own: all 256 lanes stride over it.
 // Sliced ELL (slice = 64 rows = one wave, slot-major inside the slice): exact order, coalesced.
 #include "cgh_internal.h"
@@ -222,7 +223,7 @@ static void launch_csr(const cgh_matrix *m, const double *x, double *y, double *
 int cgh_launch_spmv_csr(const cgh_matrix *m, const double *x, double *y, double *dot_partials, int *grid_out,
                         const int *done, hipStream_t s)
 {
-    const int     exact = getenv("CGH_CSR_EXACT") ? atoi(getenv("CGH_CSR_EXACT")) : 0;
+    const int     exact = m->exact_rows || (getenv("CGH_CSR_EXACT") ? atoi(getenv("CGH_CSR_EXACT")) : 0);
     const int64_t nb = m->bin_start[0];
     const int     w = (int)m->bin_start[1];   // the window the row blocks were built for
     const int     grid = cgh_stream_grid(nb, w <= 1024 ? 8 : 5);

@@ -85,8 +85,11 @@ int64_t cgh_matrix_rows(const cgh_matrix *m);
 int     cgh_matrix_width(const cgh_matrix *m);        /* K: max off-diagonals per row */
 int64_t cgh_matrix_nnz_offdiag(const cgh_matrix *m);  /* stored non-pad off-diagonals (= 2U) */
 int     cgh_matrix_layout(const cgh_matrix *m);
-int64_t cgh_matrix_stored_bytes(const cgh_matrix *m);
-int     cgh_matrix_min_row(const cgh_matrix *m);      /* shortest row of a CSR-layout matrix (-1 otherwise) */ /* HBM bytes of the matrix arrays incl. padding */
+int64_t cgh_matrix_stored_bytes(const cgh_matrix *m); /* HBM bytes of the matrix arrays incl. padding */
+int     cgh_matrix_min_row(const cgh_matrix *m);      /* shortest row of a CSR-layout matrix (-1 otherwise) */
+/* CSR layout: 1 = every row's products are added strictly left to right (the reference's order) however long the row;
+ * 0 (default) = rows of more than 64 entries use a wave/workgroup tree.  The include/cg.h, csr.h, coo.h entry points set 1. */
+int     cgh_matrix_set_exact_rows(cgh_matrix *m, int exact);
 /* Download as slot-major full ELL of width K=cgh_matrix_width (any layout); buffers hold n*K entries. */
 int     cgh_matrix_download_ell(const cgh_matrix *m, double *ell_vals, int *ell_cols);
 int     cgh_matrix_download_diag(const cgh_matrix *m, double *diag);

@@ -139,3 +139,31 @@ def powerlaw_coo(n, max_len, seed):
         vals.append(-hash01(seed + 2, np.uint64(i) * np.uint64(2048) + t[keep]))
     return dict(n=n, rows=np.concatenate(rows), cols=np.concatenate(cols), upper=np.concatenate(vals),
                 source=hash01(seed + 3, np.arange(n)) - 0.5)
+
+
+def mtx_split(path):
+    """Pure-Python restatement of the reference's inline MatrixMarket reader (tests/test_vec.c:443-560 there):
+    diag / strict-upper COO in file order, lower entries of a `symmetric` file flipped, of a `general` file dropped."""
+    with open(path) as f:
+        head = f.readline().split()
+        field, symmetry = head[3].lower(), head[4].lower()
+        line = f.readline()
+        while line.strip() == "" or line.lstrip().startswith("%"):
+            line = f.readline()
+        n, m, nz = (int(t) for t in line.split())
+        assert n == m
+        tok = f.read().split()
+    per = 2 if field == "pattern" else 3
+    diag = np.zeros(n)
+    rows, cols, vals = [], [], []
+    for k in range(nz):
+        i, j = int(tok[per * k]) - 1, int(tok[per * k + 1]) - 1
+        v = 1.0 if field == "pattern" else float(tok[per * k + 2])
+        if i == j:
+            diag[i] = v
+        elif i < j:
+            rows.append(i); cols.append(j); vals.append(v)
+        elif symmetry == "symmetric":
+            rows.append(j); cols.append(i); vals.append(v)
+    return {"n": n, "U": len(rows), "diag": diag, "upper": np.array(vals, dtype=np.float64),
+            "rows": np.array(rows, dtype=np.int32), "cols": np.array(cols, dtype=np.int32), "symmetric": symmetry == "symmetric"}
