@@ -175,8 +175,8 @@ def main():
         with open(tpath) as f:
             out["roofline"]["traffic"] = json.load(f)["hbm_bytes_per_launch"]
     sv.free()
-    # attainable ceiling next to the spec peak: device-to-device copy of 1 GiB, bytes read + written
-    cbytes = min(1 << 30, (8 * n) // 16 * 16)
+    # attainable ceiling next to the spec peak: device-to-device copy kernel, 1 GiB, bytes read + written
+    cbytes = 1 << 30                                 # far beyond the 256 MiB Infinity Cache
     src = cga.DeviceVector(cbytes // 8)
     dst = cga.DeviceVector(cbytes // 8)
     ms = C.c_double(0.0)
