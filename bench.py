@@ -164,7 +164,9 @@ def main():
                    "iter_bytes_algorithmic": int(12 * A.nnz_offdiag + 96 * n),
                    "iter_GBs_algorithmic": (12 * A.nnz_offdiag + 96 * n) / (ms_step * 1e-3) / 1e9,
                    "residual_l1_half_first_last": [float(hist[0, 0]), float(hist[-1, 0])]},
-        "roofline": {"bound": "hbm", "kernel": "spmv_ell_r2 (SpMV + p.Ap partials)", "achieved": achieved,
+        "roofline": {"bound": "hbm", "kernel": "spmv_ell_r2 (SpMV + p.Ap partials; %s)"
+                     % ("1-byte dictionary-coded columns, %d offsets" % A.dict_offsets if A.dict_offsets > 0 else "int32 columns"),
+                     "achieved": achieved,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "bytes_per_launch": int(alg_spmv), "ms_per_launch": spmv_ms, "traffic": None},
     }

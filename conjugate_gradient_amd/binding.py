@@ -61,6 +61,7 @@ def lib():
     L.cgh_matrix_powerlaw.restype = vp
     L.cgh_matrix_min_row.argtypes = [vp]
     L.cgh_matrix_set_exact_rows.argtypes = [vp, C.c_int]
+    L.cgh_matrix_dict_offsets.argtypes = [vp]
     L.cgh_matrix_free.argtypes = [vp]
     L.cgh_matrix_free.restype = None
     for f in ("cgh_matrix_rows", "cgh_matrix_nnz_offdiag", "cgh_matrix_stored_bytes"):
@@ -216,6 +217,8 @@ class Matrix:
         return cls(lib().cgh_matrix_powerlaw(n, max_len, seed, layout, b.ptr if b is not None else None))
 
     min_row = property(lambda self: lib().cgh_matrix_min_row(self.h))
+
+    dict_offsets = property(lambda self: lib().cgh_matrix_dict_offsets(self.h))
 
     def set_exact_rows(self, exact=True):
         check(lib().cgh_matrix_set_exact_rows(self.h, int(exact)), "set_exact_rows")

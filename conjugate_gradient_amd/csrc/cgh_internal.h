@@ -68,6 +68,12 @@ struct cgh_matrix {
     // CSR-adaptive row bins (row ids sorted into length classes), built once at construction
     int     *bin_rows = nullptr; // [n] row ids grouped by bin
     int64_t  bin_start[5] = {0, 0, 0, 0, 0}; // short / sub-wave / wave / block rows
+    // ELL only: dictionary-coded columns, built on the first SpMV (spmv_ell.hip).  cols8[s*n+i] = index of (col - i)
+    // in off_tab (<= 255 distinct offsets: banded / stencil matrices), 255 = pad; 1 byte per entry instead of 4.
+    mutable unsigned char *cols8 = nullptr;
+    mutable int           *off_tab = nullptr;  // [256] sorted offsets, device
+    mutable int            dict_state = 0;     // 0 not tried, 1 in use, 2 not applicable
+    mutable int            n_offsets = 0;
     bool     owns = true;
     bool     exact_rows = false;  // CSR: add every row's products strictly left to right, however long the row is
 };
@@ -92,6 +98,7 @@ static inline int cgh_stream_grid(int64_t tiles, int blocks_per_cu)
 int cgh_launch_spmv(const cgh_matrix *m, const double *x, double *y, double *dot_partials, int *grid_out,
                     const int *done_flag, hipStream_t s);
 int cgh_spmv_grid(const cgh_matrix *m);
+void cgh_ell_dict_free(const cgh_matrix *m);
 
 // convert.hip
 cgh_matrix *cgh_matrix_from_entries_device(int64_t n, int64_t U, const double *d_diag, const double *d_upper,

@@ -486,6 +486,7 @@ void cgh_dist_free(cgh_dist *d)
     cgh_free(d->mat.diag);
     cgh_free(d->mat.vals);
     cgh_free(d->mat.cols);
+    cgh_ell_dict_free(&d->mat);
     delete d;
 }
 

@@ -75,6 +75,7 @@ void cgh_matrix_free(cgh_matrix *m)
         cgh_free(m->slice_ptr);
         cgh_free(m->bin_rows);
     }
+    cgh_ell_dict_free(m);
     delete m;
 }
 

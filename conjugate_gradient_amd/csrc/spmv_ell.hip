@@ -14,6 +14,9 @@
 //
 // DOT=true additionally leaves sum_i x[i]*y[i] of the workgroup's rows in partials[blockIdx.x]
 // (CG: x is p, y is Ap; saves a full re-read of p and Ap).
+#include <algorithm>
+#include <vector>
+
 #include "cgh_internal.h"
 #include "device_utils.h"
 
@@ -37,16 +40,40 @@ __device__ __forceinline__ T stream_load(const T *p)
 // bit1 = non-temporal matrix loads, bit2 = ablation (no gather; wrong results), bit3 = non-temporal y store.
 constexpr int VAR_DEFAULT = 11;
 
-template <int KT, bool DOT, int VAR>
+// Column ids of rows i0, i0+1 in slot s (-1 = pad).  DICT: one byte per entry, an index into the table of the
+// matrix's distinct (col - row) offsets (staged in LDS), 255 = pad -- 9 instead of 12 bytes per stored entry.
+template <bool NT, bool DICT>
+__device__ __forceinline__ i2_t load_cols(const void *__restrict__ cols, const int *tab, int64_t n, int s, int64_t i0)
+{
+    if constexpr (DICT) {
+        const unsigned short cc =
+            stream_load<NT>(reinterpret_cast<const unsigned short *>(cols) + (((int64_t)s * n + i0) >> 1));
+        const int c0 = cc & 0xff, c1 = cc >> 8;
+        i2_t      c;
+        c.x = c0 != 255 ? (int)i0 + tab[c0] : -1;
+        c.y = c1 != 255 ? (int)i0 + 1 + tab[c1] : -1;
+        return c;
+    } else {
+        return stream_load<NT>(reinterpret_cast<const i2_t *>(reinterpret_cast<const int *>(cols) + (int64_t)s * n + i0));
+    }
+}
+
+template <int KT, bool DOT, int VAR, bool DICT = false>
 __global__ __launch_bounds__(CGH_BLOCK) void spmv_ell_r2(int64_t n, int Krt, const double *__restrict__ diag,
-                                                        const double *__restrict__ vals, const int *__restrict__ cols,
+                                                        const double *__restrict__ vals, const void *__restrict__ cols,
+                                                        const int *__restrict__ off_tab,
                                                         const double *__restrict__ x, double *__restrict__ y,
                                                         double *__restrict__ partials, const int *__restrict__ done,
                                                         int rev, int64_t row_begin, int64_t row_end, int64_t row_begin2,
                                                         int64_t row_end2)
 {
     __shared__ double lds[4];
+    __shared__ int    tab[DICT ? 256 : 1];
     if (done != nullptr && *done != 0) return;
+    if constexpr (DICT) {
+        tab[threadIdx.x] = off_tab[threadIdx.x];
+        __syncthreads();
+    }
     const int     K = KT > 0 ? KT : Krt;
     // rows [row_begin,row_end) followed by rows [row_begin2,row_end2) (all four even on this path): one launch serves the
     // two boundary row ranges of a multi-GPU block
@@ -79,7 +106,7 @@ __global__ __launch_bounds__(CGH_BLOCK) void spmv_ell_r2(int64_t n, int Krt, con
             i2_t c[KT];
 #pragma unroll
             for (int s = 0; s < KT; ++s) {
-                c[s] = stream_load<NT>(reinterpret_cast<const i2_t *>(cols + (int64_t)s * n + i0));
+                c[s] = load_cols<NT, DICT>(cols, tab, n, s, i0);
                 v[s] = stream_load<NT>(reinterpret_cast<const d2_t *>(vals + (int64_t)s * n + i0));
             }
             double g0[KT], g1[KT];
@@ -103,7 +130,7 @@ __global__ __launch_bounds__(CGH_BLOCK) void spmv_ell_r2(int64_t n, int Krt, con
         } else {
 #pragma unroll 4
             for (int s = 0; s < K; ++s) {
-                const i2_t    c = stream_load<NT>(reinterpret_cast<const i2_t *>(cols + (int64_t)s * n + i0));
+                const i2_t    c = load_cols<NT, DICT>(cols, tab, n, s, i0);
                 const d2_t    v = stream_load<NT>(reinterpret_cast<const d2_t *>(vals + (int64_t)s * n + i0));
                 const double  g0 = x[c.x >= 0 ? (int64_t)c.x : i0];
                 const double  g1 = x[c.y >= 0 ? (int64_t)c.y : i0];
@@ -162,14 +189,15 @@ __global__ __launch_bounds__(CGH_BLOCK) void spmv_ell_r1(int64_t n, int K, const
 
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
-template <bool DOT, int VAR>
-void launch_r2(int K, int grid, hipStream_t s, int64_t n, const double *diag, const double *vals, const int *cols,
-               const double *x, double *y, double *partials, const int *done, int64_t rb, int64_t re, int64_t rb2, int64_t re2)
+template <bool DOT, int VAR, bool DICT = false>
+void launch_r2(int K, int grid, hipStream_t s, int64_t n, const double *diag, const double *vals, const void *cols,
+               const int *off_tab, const double *x, double *y, double *partials, const int *done, int64_t rb, int64_t re,
+               int64_t rb2, int64_t re2)
 {
 #define CGH_ELL_CASE(KK)                                                                                       \
     case KK:                                                                                                   \
-        hipLaunchKernelGGL((spmv_ell_r2<KK, DOT, VAR>), dim3(grid), dim3(CGH_BLOCK), 0, s, n, K, diag, vals, cols, x, y, \
-                           partials, done, g_cgh.sweep_reverse, rb, re, rb2, re2);                                                                    \
+        hipLaunchKernelGGL((spmv_ell_r2<KK, DOT, VAR, DICT>), dim3(grid), dim3(CGH_BLOCK), 0, s, n, K, diag, vals, cols, \
+                           off_tab, x, y, partials, done, g_cgh.sweep_reverse, rb, re, rb2, re2);                     \
         break;
     static const int generic = getenv("CGH_ELL_GENERIC") ? atoi(getenv("CGH_ELL_GENERIC")) : 0;
     switch (generic ? -1 : K) {
@@ -184,13 +212,126 @@ void launch_r2(int K, int grid, hipStream_t s, int64_t n, const double *diag, co
         CGH_ELL_CASE(13)
         CGH_ELL_CASE(26)
     default:
-        hipLaunchKernelGGL((spmv_ell_r2<0, DOT, VAR>), dim3(grid), dim3(CGH_BLOCK), 0, s, n, K, diag, vals, cols, x, y,
-                           partials, done, g_cgh.sweep_reverse, rb, re, rb2, re2);
+        hipLaunchKernelGGL((spmv_ell_r2<0, DOT, VAR, DICT>), dim3(grid), dim3(CGH_BLOCK), 0, s, n, K, diag, vals, cols, off_tab,
+                           x, y, partials, done, g_cgh.sweep_reverse, rb, re, rb2, re2);
     }
 #undef CGH_ELL_CASE
 }
 
+// ------------------------------------------------------------------------------- dictionary-coded columns
+constexpr int DICT_SLOTS = 512, DICT_EMPTY = INT32_MIN;
+
+// distinct (col - row) offsets -> open-addressing table; gives up (overflow) beyond 255
+__global__ __launch_bounds__(256) void dict_collect(int64_t total, int64_t n, const int *__restrict__ cols, int *table, int *count,
+                                                   int *overflow)
+{
+    for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < total; k += (int64_t)gridDim.x * 256) {
+        if (__atomic_load_n(overflow, __ATOMIC_RELAXED)) return;
+        const int c = cols[k];
+        if (c == -1) continue;
+        const int off = c - (int)(k % n);
+        unsigned  h = ((unsigned)off * 2654435761u) >> 23;  // 9 bits
+        for (int probe = 0;; ++probe) {
+            if (probe == DICT_SLOTS) {
+                atomicExch(overflow, 1);
+                return;
+            }
+            int cur = __atomic_load_n(&table[h], __ATOMIC_RELAXED);
+            if (cur == DICT_EMPTY) {
+                cur = atomicCAS(&table[h], DICT_EMPTY, off);
+                if (cur == DICT_EMPTY) {
+                    if (atomicAdd(count, 1) >= 255) atomicExch(overflow, 1);
+                    break;
+                }
+            }
+            if (cur == off) break;
+            h = (h + 1) & (DICT_SLOTS - 1);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void dict_encode(int64_t total, int64_t n, const int *__restrict__ cols,
+                                                  const int *__restrict__ sorted, int count, unsigned char *__restrict__ out)
+{
+    __shared__ int tab[256];
+    tab[threadIdx.x] = (int)threadIdx.x < count ? sorted[threadIdx.x] : INT32_MAX;
+    __syncthreads();
+    for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < total; k += (int64_t)gridDim.x * 256) {
+        const int c = cols[k];
+        int       code = 255;
+        if (c != -1) {
+            const int off = c - (int)(k % n);
+            int       lo = 0, hi = count - 1;
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (tab[mid] < off) lo = mid + 1;
+                else hi = mid;
+            }
+            code = lo;
+        }
+        out[k] = (unsigned char)code;
+    }
+}
+
+// Build m->cols8 / m->off_tab if the matrix has at most 255 distinct diagonals.  Synchronises the stream.
+void ell_dict_try_build(const cgh_matrix *m, hipStream_t s)
+{
+    m->dict_state = 2;
+    const int     enabled = getenv("CGH_ELL_DICT") ? atoi(getenv("CGH_ELL_DICT")) : 1;  // read per matrix (tests toggle it)
+    const int64_t total = m->n * (int64_t)m->K;
+    if (!enabled || m->K <= 0 || total < 2) return;
+    int *work = (int *)cgh_alloc(sizeof(int) * (DICT_SLOTS + 2));
+    if (!work) return;
+    std::vector<int> h(DICT_SLOTS + 2, DICT_EMPTY);
+    h[DICT_SLOTS] = h[DICT_SLOTS + 1] = 0;
+    const int grid = cgh_stream_grid((total + 255) / 256, 8);
+    bool      ok = cgh_h2d(work, h.data(), sizeof(int) * h.size()) == CGH_OK;
+    if (ok) {
+        hipLaunchKernelGGL(dict_collect, dim3(grid), dim3(256), 0, s, total, m->n, (const int *)m->cols, work, work + DICT_SLOTS,
+                           work + DICT_SLOTS + 1);
+        ok = hipGetLastError() == hipSuccess && cgh_d2h(h.data(), work, sizeof(int) * h.size()) == CGH_OK;
+    }
+    cgh_free(work);
+    if (!ok || h[DICT_SLOTS + 1] != 0 || h[DICT_SLOTS] > 255) return;
+    std::vector<int> offs;
+    for (int k = 0; k < DICT_SLOTS; ++k)
+        if (h[k] != DICT_EMPTY) offs.push_back(h[k]);
+    std::sort(offs.begin(), offs.end());
+    const int count = (int)offs.size();
+    offs.resize(256, 0);
+    m->off_tab = (int *)cgh_alloc(sizeof(int) * 256);
+    m->cols8 = (unsigned char *)cgh_alloc((size_t)total);
+    if (!m->off_tab || !m->cols8 || cgh_h2d(m->off_tab, offs.data(), sizeof(int) * 256) != CGH_OK) {
+        cgh_ell_dict_free(m);
+        return;
+    }
+    hipLaunchKernelGGL(dict_encode, dim3(grid), dim3(256), 0, s, total, m->n, (const int *)m->cols, (const int *)m->off_tab, count,
+                       m->cols8);
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
+        cgh_ell_dict_free(m);
+        return;
+    }
+    m->n_offsets = count;
+    m->dict_state = 1;
+}
+
 } // namespace
+
+extern "C" int cgh_matrix_dict_offsets(const cgh_matrix *m)
+{
+    if (!m || m->layout != CGH_LAYOUT_ELL) return -1;
+    return m->dict_state == 0 ? -1 : (m->dict_state == 1 ? m->n_offsets : 0);
+}
+
+void cgh_ell_dict_free(const cgh_matrix *m)
+{
+    if (!m) return;
+    cgh_free(m->cols8);
+    cgh_free(m->off_tab);
+    m->cols8 = nullptr;
+    m->off_tab = nullptr;
+    if (m->dict_state == 1) m->dict_state = 2;
+}
 
 // Rows per thread on the vector path.
 static inline bool ell_vector_path(const cgh_matrix *m, const double *x, const double *y)
@@ -240,6 +381,21 @@ int cgh_launch_spmv_ell_range2(const cgh_matrix *m, const double *x, double *y, 
         return rc;
     }
     if (ell_vector_path(m, x, y) && rb % 2 == 0 && re % 2 == 0 && rb2 % 2 == 0 && re2 % 2 == 0) {
+        if (m->dict_state == 0) {
+            hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+            (void)hipStreamIsCapturing(s, &cap);
+            if (cap == hipStreamCaptureStatusNone) ell_dict_try_build(m, s);
+        }
+        if (m->dict_state == 1) {
+            if (dot_partials)
+                launch_r2<true, VAR_DEFAULT, true>(m->K, grid, s, m->n, m->diag, m->vals, m->cols8, m->off_tab, x, y, dot_partials,
+                                                   done, rb, re, rb2, re2);
+            else
+                launch_r2<false, VAR_DEFAULT, true>(m->K, grid, s, m->n, m->diag, m->vals, m->cols8, m->off_tab, x, y, nullptr, done,
+                                                    rb, re, rb2, re2);
+            CGH_HIP(hipGetLastError());
+            return CGH_OK;
+        }
         static const int var = [] {
             const int v = getenv("CGH_ELL_VARIANT") ? atoi(getenv("CGH_ELL_VARIANT")) : VAR_DEFAULT;
             return (v == 0 || v == 1 || v == 2 || v == 3 || v == 7 || v == 11) ? v : VAR_DEFAULT;
@@ -247,9 +403,9 @@ int cgh_launch_spmv_ell_range2(const cgh_matrix *m, const double *x, double *y, 
 #define CGH_ELL_VAR(V)                                                                                                  \
     case V:                                                                                                             \
         if (dot_partials)                                                                                               \
-            launch_r2<true, V>(m->K, grid, s, m->n, m->diag, m->vals, m->cols, x, y, dot_partials, done, rb, re, rb2, re2); \
+            launch_r2<true, V>(m->K, grid, s, m->n, m->diag, m->vals, m->cols, nullptr, x, y, dot_partials, done, rb, re, rb2, re2); \
         else                                                                                                            \
-            launch_r2<false, V>(m->K, grid, s, m->n, m->diag, m->vals, m->cols, x, y, nullptr, done, rb, re, rb2, re2); \
+            launch_r2<false, V>(m->K, grid, s, m->n, m->diag, m->vals, m->cols, nullptr, x, y, nullptr, done, rb, re, rb2, re2); \
         break;
         switch (var) {
             CGH_ELL_VAR(0)

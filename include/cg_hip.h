@@ -90,6 +90,10 @@ int     cgh_matrix_min_row(const cgh_matrix *m);      /* shortest row of a CSR-l
 /* CSR layout: 1 = every row's products are added strictly left to right (the reference's order) however long the row;
  * 0 (default) = rows of more than 64 entries use a wave/workgroup tree.  The include/cg.h, csr.h, coo.h entry points set 1. */
 int     cgh_matrix_set_exact_rows(cgh_matrix *m, int exact);
+/* ELL layout: the SpMV reads 1-byte dictionary codes instead of 4-byte column ids when the matrix has at most 255
+ * distinct (col - row) offsets (banded / stencil matrices; built on the first SpMV; CGH_ELL_DICT=0 disables).  Returns the
+ * number of distinct offsets in use, 0 if the matrix does not qualify, -1 before the first SpMV / other layouts. */
+int     cgh_matrix_dict_offsets(const cgh_matrix *m);
 /* Download as slot-major full ELL of width K=cgh_matrix_width (any layout); buffers hold n*K entries. */
 int     cgh_matrix_download_ell(const cgh_matrix *m, double *ell_vals, int *ell_cols);
 int     cgh_matrix_download_diag(const cgh_matrix *m, double *diag);

@@ -118,3 +118,47 @@ def test_poisson_256_conversion_matches_direct_generator(cga):
     bh, xh = b.to_host(), xs.to_host()
     lhs, rhs = np.dot(xh, ref), np.dot(bh, Ax.to_host())
     assert abs(lhs - rhs) <= 1e-9 * max(abs(lhs), 1.0)
+
+
+@pytest.mark.parametrize("case", ["poisson7", "poisson27", "banded_random", "unstructured", "foam"])
+def test_dictionary_coded_columns_same_bits(cga, monkeypatch, case):
+    """ELL SpMV with 1-byte dictionary codes for the column ids (matrices with <= 255 distinct diagonals) gives the
+    same bits as the int32 columns; matrices with more distinct offsets keep int32 columns."""
+    rng = np.random.default_rng(8)
+    if case == "poisson7":
+        s = foamio.poisson_coo(20, 14, 10, 0x5EED0001, 7)
+    elif case == "poisson27":
+        s = foamio.poisson_coo(12, 10, 8, 0x5EED0001, 27)
+    elif case == "foam":
+        s = foamio.foam("8000")
+    else:
+        n = 6000
+        offs = rng.choice(np.arange(1, 3000), 40, replace=False) if case == "banded_random" else None
+        rr, cc = [], []
+        for i in range(n - 1):
+            if offs is not None:
+                js = i + offs[rng.random(offs.size) < 0.2]
+            else:
+                js = rng.integers(i + 1, n, 3)
+            js = np.unique(js[js < n])
+            rr += [i] * js.size; cc += list(js)
+        rows = np.array(rr, dtype=np.int32); cols = np.array(cc, dtype=np.int32)
+        s = {"n": n, "U": rows.size, "rows": rows, "cols": cols, "upper": rng.standard_normal(rows.size),
+             "diag": rng.standard_normal(n) + 5.0}
+    n = s["n"]
+    xh = rng.standard_normal(n)
+    x = cga.DeviceVector.from_host(xh); y = cga.DeviceVector(n)
+    out = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("CGH_ELL_DICT", flag)
+        A = cga.Matrix.from_coo(n, s["diag"], s["upper"], s["rows"], s["cols"], cga.LAYOUT_ELL)
+        assert A.dict_offsets == -1
+        A.spmv(x, y)
+        out[flag] = (y.to_host(), A.dict_offsets)
+    want = O.mv_coo(n, s["diag"], s["upper"], s["rows"], s["cols"], xh)
+    assert np.array_equal(bits(out["0"][0]), bits(want)) and np.array_equal(bits(out["1"][0]), bits(want))
+    assert out["0"][1] == 0
+    if case in ("poisson7", "poisson27", "banded_random"):
+        assert 0 < out["1"][1] <= 255
+    elif case == "unstructured":
+        assert out["1"][1] == 0
