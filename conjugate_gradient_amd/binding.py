@@ -16,7 +16,7 @@ ip = C.POINTER(C.c_int)
 
 class CgOpts(C.Structure):
     _fields_ = [("max_iter", C.c_int), ("tol", C.c_double), ("strict", C.c_int),
-                ("check_every", C.c_int), ("fixed_iters", C.c_int), ("time_kernels", C.c_int)]
+                ("check_every", C.c_int), ("fixed_iters", C.c_int), ("time_kernels", C.c_int), ("precond", C.c_int)]
 
 
 class CgReport(C.Structure):
@@ -81,6 +81,7 @@ def lib():
     L.cgh_solver_free.argtypes = [vp]
     L.cgh_solver_free.restype = None
     L.cgh_solver_start.argtypes = [vp, vp, vp, C.c_double, C.c_int]
+    L.cgh_solver_set_precond.argtypes = [vp, C.c_int]
     L.cgh_solver_iterate.argtypes = [vp, C.c_int, C.c_int]
     L.cgh_solver_poll.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.cgh_solver_history.argtypes = [vp, C.c_int, C.c_int, dp]
@@ -255,9 +256,9 @@ class Matrix:
 
 
 def cg_solve(mat, b, x, max_iter=1000, tol=1e-6, strict=0, check_every=0, fixed_iters=0, time_kernels=0,
-             history=True):
+             history=True, precond=0):
     """-> (CgReport, history[iterations+1, 4] or None)"""
-    opts = CgOpts(max_iter, tol, strict, check_every, fixed_iters, time_kernels)
+    opts = CgOpts(max_iter, tol, strict, check_every, fixed_iters, time_kernels, precond)
     rep = CgReport()
     cap = (fixed_iters + 2) if fixed_iters > 0 else max_iter + 1
     hist = np.full((cap, 4), np.nan) if history else None

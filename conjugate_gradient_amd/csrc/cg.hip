@@ -94,6 +94,7 @@ struct cgh_solver {
     int               queued = 0;     // iterations queued since start
     int               vgrid = 0;
     bool              strict = false;
+    int               precond = CGH_PRECOND_NONE;
     double            tol = 0.0;
     double           *x = nullptr;    // caller's solution vector
     double           *r = nullptr, *p = nullptr, *Ap = nullptr;
@@ -193,6 +194,17 @@ void cgh_solver_free(cgh_solver *sv)
     delete sv;
 }
 
+// Preconditioner of the next cgh_solver_start (additive; the reference has none).
+int cgh_solver_set_precond(cgh_solver *sv, int kind)
+{
+    if (!sv || (kind != CGH_PRECOND_NONE && kind != CGH_PRECOND_JACOBI)) {
+        cgh_set_error("cgh_solver_set_precond: unknown preconditioner %d", kind);
+        return CGH_EINVAL;
+    }
+    sv->precond = kind;
+    return CGH_OK;
+}
+
 // x = 0; r = b - A x; p = r; rr = r.r (reference cg.c:433-456).  Asynchronous.
 int cgh_solver_start(cgh_solver *sv, const double *d_b, double *d_x, double tol, int strict)
 {
@@ -219,8 +231,17 @@ int cgh_solver_start(cgh_solver *sv, const double *d_b, double *d_x, double tol,
     CGH_HIP(hipMemsetAsync(d_x, 0, sizeof(double) * (size_t)n, s));
     int rc = cgh_launch_spmv(sv->m, d_x, sv->Ap, nullptr, nullptr, nullptr, s);
     if (rc) return rc;
-    hipLaunchKernelGGL(cg_init_rp, dim3(sv->vgrid), dim3(CGH_BLOCK), 0, s, n, d_b, (const double *)sv->Ap, sv->r, sv->p,
-                       sv->partB);
+    if (sv->precond == CGH_PRECOND_JACOBI) {
+        if (sv->strict) {
+            cgh_set_error("cgh_solver_start: the Jacobi preconditioner has no reference order to be strict about (use strict=0)");
+            return CGH_EINVAL;
+        }
+        if (n & 1 ? false : (reinterpret_cast<uintptr_t>(sv->m->diag) & 15u) != 0) return CGH_EINVAL;
+        hipLaunchKernelGGL(pcg_init_rp, dim3(sv->vgrid), dim3(CGH_BLOCK), 0, s, n, d_b, (const double *)sv->Ap,
+                           (const double *)sv->m->diag, sv->r, sv->p, sv->partB);
+    } else
+        hipLaunchKernelGGL(cg_init_rp, dim3(sv->vgrid), dim3(CGH_BLOCK), 0, s, n, d_b, (const double *)sv->Ap, sv->r, sv->p,
+                           sv->partB);
     if (sv->strict) {
         if (!sv->xs && n >= xsum_min_rows()) {
             sv->xs = cgh_xsum_create(n);
@@ -268,7 +289,13 @@ static int enqueue_iterations(cgh_solver *sv, int count, int time_kernels, bool 
         if (rc) return rc;
         g_cgh.sweep_reverse = 0;
         if (time_kernels) CGH_HIP(hipEventRecord(sv->kev.back(), s));
-        if (sv->strict) {
+        if (sv->precond == CGH_PRECOND_JACOBI) {
+            const double *dg = sv->m->diag;
+            hipLaunchKernelGGL(pcg_update_xr, dim3(vg), dim3(CGH_BLOCK), 0, s, n, d_x, (const double *)dp, dr, (const double *)dAp, dg,
+                               (const double *)dA, gridA, dB, dh, iter, (const int *)dd);
+            hipLaunchKernelGGL(pcg_update_p, dim3(vg), dim3(CGH_BLOCK), 0, s, n, (const double *)dr, dp, dg, (const double *)dB, vg,
+                               dh, iter, tol, dd);
+        } else if (sv->strict) {
             rc = strict_sums(sv, dp, dAp, nullptr, 1, iter, s);
             if (rc) return rc;
             hipLaunchKernelGGL((cg_update_xr<1, 3>), dim3(vg), dim3(CGH_BLOCK), 0, s, n, d_x, (const double *)dp, dr,
@@ -412,7 +439,9 @@ int cgh_cg_solve(const cgh_matrix *m, const double *d_b, double *d_x, const cgh_
         ~guard() { cgh_solver_free(p); }
     } g{sv};
     hipStream_t s = g_cgh.stream;
-    int         rc = cgh_solver_start(sv, d_b, d_x, tol, opts->strict);
+    int         rc = cgh_solver_set_precond(sv, opts->precond);
+    if (rc) return rc;
+    rc = cgh_solver_start(sv, d_b, d_x, tol, opts->strict);
     if (rc) return rc;
     CGH_HIP(hipMemcpyAsync(rep->r0, sv->r, sizeof(double) * (m->n < 5 ? m->n : 5), hipMemcpyDeviceToHost, s));
 

@@ -201,6 +201,104 @@ __global__ __launch_bounds__(CGH_BLOCK) void cg_update_p(int64_t n, const double
     if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) p[n - 1] = madd_rn(r[n - 1], beta, p[n - 1]);
 }
 
+// ---------------------------------------------------------------- Jacobi-preconditioned variant
+//
+// No reference counterpart (the reference is "nonePCG"); off by default.  z = r / diag is never stored: the three
+// kernels divide on the fly.  Same structure, history layout and stop test (l1norm(r)/2 < tol) as the plain loop;
+// history[.][1] holds r.z instead of r.r.  Throughput-mode reductions only.
+__global__ __launch_bounds__(CGH_BLOCK) void pcg_init_rp(int64_t n, const double *__restrict__ b, const double *__restrict__ Ap0,
+                                                        const double *__restrict__ dg, double *__restrict__ r,
+                                                        double *__restrict__ p, double *__restrict__ partials)
+{
+    __shared__ double lds[4];
+    double            rz = 0.0, l1 = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * CGH_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * CGH_BLOCK) {
+        const double v = b[i] - Ap0[i];
+        const double z = v / dg[i];
+        r[i] = v;
+        p[i] = z;
+        rz += v * z;
+        l1 += fabs(v);
+    }
+    const double trz = block_sum_256(rz, lds);
+    const double tl1 = block_sum_256(l1, lds);
+    if (threadIdx.x == 0) {
+        partials[2 * blockIdx.x] = trz;
+        partials[2 * blockIdx.x + 1] = tl1;
+    }
+}
+
+__global__ __launch_bounds__(CGH_BLOCK) void pcg_update_xr(int64_t n, double *__restrict__ x, const double *__restrict__ p,
+                                                          double *__restrict__ r, const double *__restrict__ Ap,
+                                                          const double *__restrict__ dg, const double *__restrict__ pAp_partials,
+                                                          int pAp_count, double *__restrict__ out_partials, double *hist, int iter,
+                                                          const int *__restrict__ done)
+{
+    __shared__ double lds[4];
+    if (*done != 0) return;
+    if (iter == 0) iter = done[2] + 1;
+    if (blockIdx.x == 0 && threadIdx.x == 0) const_cast<int *>(done)[1] = iter;
+    const double pAp = block_sum_partials(pAp_partials, pAp_count, 1, lds);
+    const double alpha = hist[(size_t)(iter - 1) * HIST + 1] / pAp;
+    if (blockIdx.x == 0 && threadIdx.x == 0) hist[(size_t)iter * HIST + 2] = alpha;
+    const double nalpha = -alpha;
+    double       rz = 0.0, l1 = 0.0;
+    const int64_t pairs = n >> 1;
+    for (int64_t k = (int64_t)blockIdx.x * CGH_BLOCK + threadIdx.x; k < pairs; k += (int64_t)gridDim.x * CGH_BLOCK) {
+        const double2 xv = ld2<1>(x, k), pv = ld2<1>(p, k), rv = ld2<1>(r, k), av = ld2<1>(Ap, k), dv = ld2<1>(dg, k);
+        const double2 xn = make_double2(madd_rn(xv.x, alpha, pv.x), madd_rn(xv.y, alpha, pv.y));
+        const double2 rn = make_double2(madd_rn(rv.x, nalpha, av.x), madd_rn(rv.y, nalpha, av.y));
+        st2<true>(x, k, xn.x, xn.y);
+        st2<false>(r, k, rn.x, rn.y);
+        rz += rn.x * (rn.x / dv.x) + rn.y * (rn.y / dv.y);
+        l1 += fabs(rn.x) + fabs(rn.y);
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+        const int64_t i = n - 1;
+        const double  xn = madd_rn(x[i], alpha, p[i]), rn = madd_rn(r[i], nalpha, Ap[i]);
+        x[i] = xn;
+        r[i] = rn;
+        rz += rn * (rn / dg[i]);
+        l1 += fabs(rn);
+    }
+    const double trz = block_sum_256(rz, lds);
+    const double tl1 = block_sum_256(l1, lds);
+    if (threadIdx.x == 0) {
+        out_partials[2 * blockIdx.x] = trz;
+        out_partials[2 * blockIdx.x + 1] = tl1;
+    }
+}
+
+__global__ __launch_bounds__(CGH_BLOCK) void pcg_update_p(int64_t n, const double *__restrict__ r, double *__restrict__ p,
+                                                         const double *__restrict__ dg, const double *__restrict__ partials,
+                                                         int count, double *hist, int iter, double tol, int *done)
+{
+    __shared__ double lds[4];
+    if (*done != 0) return;
+    if (iter == 0) iter = done[1];
+    if (blockIdx.x == 0 && threadIdx.x == 0) done[2] = iter;
+    const double rz = block_sum_partials(partials, count, 2, lds);
+    const double l1 = block_sum_partials(partials + 1, count, 2, lds);
+    const double res = l1 / 2.0;
+    const bool   conv = res < tol;
+    const double beta = rz / hist[(size_t)(iter - 1) * HIST + 1];
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        hist[(size_t)iter * HIST + 0] = res;
+        hist[(size_t)iter * HIST + 1] = rz;
+        hist[(size_t)iter * HIST + 3] = conv ? NAN : beta;
+    }
+    if (conv) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) *done = iter;
+        return;
+    }
+    const int64_t pairs = n >> 1;
+    for (int64_t k = (int64_t)blockIdx.x * CGH_BLOCK + threadIdx.x; k < pairs; k += (int64_t)gridDim.x * CGH_BLOCK) {
+        const double2 rv = ld2<1>(r, k), pv = ld2<1>(p, k), dv = ld2<1>(dg, k);
+        st2<false>(p, k, madd_rn(rv.x / dv.x, beta, pv.x), madd_rn(rv.y / dv.y, beta, pv.y));
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) p[n - 1] = madd_rn(r[n - 1] / dg[n - 1], beta, p[n - 1]);
+}
+
 // ---------------------------------------------------------------- strict (sequential-order) sums
 //
 // One workgroup.  All 256 threads stage rounded products a[i]*b[i] (and |c[i]|) of a 2048-element

@@ -120,7 +120,10 @@ typedef struct cgh_cg_opts {
                              The device freezes x at the converging iteration, so the result does not depend on this. */
     int    fixed_iters;   /* >0: run exactly this many iterations, never test convergence (benchmark mode) */
     int    time_kernels;  /* 1: bracket the SpMV kernel of every iteration with HIP events (benchmark mode) */
+    int    precond;       /* CGH_PRECOND_NONE (0, the reference's loop) or CGH_PRECOND_JACOBI: z = r/diag, p = z + beta p,
+                             alpha = r.z/(p.Ap); no reference counterpart, strict must be 0; history[.][1] = r.z */
 } cgh_cg_opts;
+enum { CGH_PRECOND_NONE = 0, CGH_PRECOND_JACOBI = 1 };
 
 typedef struct cgh_cg_report {
     int    ret;           /* iter+1 on convergence, -1 otherwise (reference convention) */
@@ -142,6 +145,7 @@ int cgh_cg_solve(const cgh_matrix *m, const double *d_b, double *d_x,
 typedef struct cgh_solver cgh_solver;
 cgh_solver   *cgh_solver_create(const cgh_matrix *m, int iteration_capacity);
 void          cgh_solver_free(cgh_solver *s);
+int           cgh_solver_set_precond(cgh_solver *s, int kind);   /* before cgh_solver_start; default CGH_PRECOND_NONE */
 int           cgh_solver_start(cgh_solver *s, const double *d_b, double *d_x, double tol, int strict);
 int           cgh_solver_iterate(cgh_solver *s, int count, int time_kernels);
 int           cgh_solver_poll(cgh_solver *s, int *done_iter, int *queued);
