@@ -74,6 +74,7 @@ struct cgh_matrix {
     mutable int           *off_tab = nullptr;  // [256] sorted offsets, device
     mutable int            dict_state = 0;     // 0 not tried, 1 in use, 2 not applicable
     mutable int            n_offsets = 0;
+    mutable int            dict_mode = 0;      // 1: cols8 = one byte per entry (slot-major); 2: 4 slots of a row per 32-bit word
     bool     owns = true;
     bool     exact_rows = false;  // CSR: add every row's products strictly left to right, however long the row is
 };

@@ -24,6 +24,7 @@ namespace {
 
 typedef double d2_t __attribute__((ext_vector_type(2)));
 typedef int    i2_t __attribute__((ext_vector_type(2)));
+typedef unsigned u2_t __attribute__((ext_vector_type(2)));
 
 // Matrix values/columns are read exactly once per SpMV: non-temporal loads keep them from
 // displacing the gathered x lines in L2.
@@ -42,10 +43,10 @@ constexpr int VAR_DEFAULT = 11;
 
 // Column ids of rows i0, i0+1 in slot s (-1 = pad).  DICT: one byte per entry, an index into the table of the
 // matrix's distinct (col - row) offsets (staged in LDS), 255 = pad -- 9 instead of 12 bytes per stored entry.
-template <bool NT, bool DICT>
+template <bool NT, int DICT>
 __device__ __forceinline__ i2_t load_cols(const void *__restrict__ cols, const int *tab, int64_t n, int s, int64_t i0)
 {
-    if constexpr (DICT) {
+    if constexpr (DICT == 1) {
         const unsigned short cc =
             stream_load<NT>(reinterpret_cast<const unsigned short *>(cols) + (((int64_t)s * n + i0) >> 1));
         const int c0 = cc & 0xff, c1 = cc >> 8;
@@ -58,7 +59,7 @@ __device__ __forceinline__ i2_t load_cols(const void *__restrict__ cols, const i
     }
 }
 
-template <int KT, bool DOT, int VAR, bool DICT = false>
+template <int KT, bool DOT, int VAR, int DICT = 0>
 __global__ __launch_bounds__(CGH_BLOCK) void spmv_ell_r2(int64_t n, int Krt, const double *__restrict__ diag,
                                                         const double *__restrict__ vals, const void *__restrict__ cols,
                                                         const int *__restrict__ off_tab,
@@ -70,7 +71,7 @@ __global__ __launch_bounds__(CGH_BLOCK) void spmv_ell_r2(int64_t n, int Krt, con
     __shared__ double lds[4];
     __shared__ int    tab[DICT ? 256 : 1];
     if (done != nullptr && *done != 0) return;
-    if constexpr (DICT) {
+    if constexpr (DICT != 0) {
         tab[threadIdx.x] = off_tab[threadIdx.x];
         __syncthreads();
     }
@@ -104,10 +105,28 @@ __global__ __launch_bounds__(CGH_BLOCK) void spmv_ell_r2(int64_t n, int Krt, con
         if constexpr (KT > 0) {
             d2_t v[KT];
             i2_t c[KT];
+            if constexpr (DICT == 2) {
+                // wide rows: the codes of 4 slots of one row share a 32-bit word (word q of row i at q*n+i), so a lane
+                // fetches 8 bytes per 4 slots of its row pair instead of four 2-byte loads
+                constexpr int NW = (KT + 3) / 4;
+                u2_t          w[NW];
 #pragma unroll
-            for (int s = 0; s < KT; ++s) {
-                c[s] = load_cols<NT, DICT>(cols, tab, n, s, i0);
-                v[s] = stream_load<NT>(reinterpret_cast<const d2_t *>(vals + (int64_t)s * n + i0));
+                for (int q = 0; q < NW; ++q)
+                    w[q] = stream_load<NT>(reinterpret_cast<const u2_t *>(reinterpret_cast<const unsigned *>(cols) + (int64_t)q * n + i0));
+#pragma unroll
+                for (int s = 0; s < KT; ++s) v[s] = stream_load<NT>(reinterpret_cast<const d2_t *>(vals + (int64_t)s * n + i0));
+#pragma unroll
+                for (int s = 0; s < KT; ++s) {
+                    const int c0 = (w[s >> 2].x >> (8 * (s & 3))) & 0xff, c1 = (w[s >> 2].y >> (8 * (s & 3))) & 0xff;
+                    c[s].x = c0 != 255 ? (int)i0 + tab[c0] : -1;
+                    c[s].y = c1 != 255 ? (int)i0 + 1 + tab[c1] : -1;
+                }
+            } else {
+#pragma unroll
+                for (int s = 0; s < KT; ++s) {
+                    c[s] = load_cols<NT, DICT>(cols, tab, n, s, i0);
+                    v[s] = stream_load<NT>(reinterpret_cast<const d2_t *>(vals + (int64_t)s * n + i0));
+                }
             }
             double g0[KT], g1[KT];
 #pragma unroll
@@ -128,9 +147,20 @@ __global__ __launch_bounds__(CGH_BLOCK) void spmv_ell_r2(int64_t n, int Krt, con
                 a1 = c[s].y >= 0 ? t1 : a1;
             }
         } else {
+            u2_t w;
+            w.x = w.y = 0;
 #pragma unroll 4
             for (int s = 0; s < K; ++s) {
-                const i2_t    c = load_cols<NT, DICT>(cols, tab, n, s, i0);
+                i2_t c;
+                if constexpr (DICT == 2) {
+                    if ((s & 3) == 0)
+                        w = stream_load<NT>(reinterpret_cast<const u2_t *>(reinterpret_cast<const unsigned *>(cols) + (int64_t)(s >> 2) * n + i0));
+                    const int c0 = (w.x >> (8 * (s & 3))) & 0xff, c1 = (w.y >> (8 * (s & 3))) & 0xff;
+                    c.x = c0 != 255 ? (int)i0 + tab[c0] : -1;
+                    c.y = c1 != 255 ? (int)i0 + 1 + tab[c1] : -1;
+                } else {
+                    c = load_cols<NT, DICT>(cols, tab, n, s, i0);
+                }
                 const d2_t    v = stream_load<NT>(reinterpret_cast<const d2_t *>(vals + (int64_t)s * n + i0));
                 const double  g0 = x[c.x >= 0 ? (int64_t)c.x : i0];
                 const double  g1 = x[c.y >= 0 ? (int64_t)c.y : i0];
@@ -189,7 +219,7 @@ __global__ __launch_bounds__(CGH_BLOCK) void spmv_ell_r1(int64_t n, int K, const
 
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
-template <bool DOT, int VAR, bool DICT = false>
+template <bool DOT, int VAR, int DICT = 0>
 void launch_r2(int K, int grid, hipStream_t s, int64_t n, const double *diag, const double *vals, const void *cols,
                const int *off_tab, const double *x, double *y, double *partials, const int *done, int64_t rb, int64_t re,
                int64_t rb2, int64_t re2)
@@ -273,6 +303,38 @@ __global__ __launch_bounds__(256) void dict_encode(int64_t total, int64_t n, con
     }
 }
 
+// packed layout: word q of row i (at q*n+i) = codes of slots 4q..4q+3 of that row, low byte first; 255 beyond K
+__global__ __launch_bounds__(256) void dict_encode_packed(int64_t n, int K, const int *__restrict__ cols, const int *__restrict__ sorted,
+                                                         int count, unsigned *__restrict__ out)
+{
+    __shared__ int tab[256];
+    tab[threadIdx.x] = (int)threadIdx.x < count ? sorted[threadIdx.x] : INT32_MAX;
+    __syncthreads();
+    const int64_t words = (int64_t)((K + 3) / 4) * n;
+    for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < words; k += (int64_t)gridDim.x * 256) {
+        const int64_t i = k % n;
+        const int     q = (int)(k / n);
+        unsigned      word = 0;
+        for (int j = 0; j < 4; ++j) {
+            const int sl = 4 * q + j;
+            int       code = 255;
+            const int c = sl < K ? cols[(int64_t)sl * n + i] : -1;
+            if (c != -1) {
+                const int off = c - (int)i;
+                int       lo = 0, hi = count - 1;
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    if (tab[mid] < off) lo = mid + 1;
+                    else hi = mid;
+                }
+                code = lo;
+            }
+            word |= (unsigned)code << (8 * j);
+        }
+        out[k] = word;
+    }
+}
+
 // Build m->cols8 / m->off_tab if the matrix has at most 255 distinct diagonals.  Synchronises the stream.
 void ell_dict_try_build(const cgh_matrix *m, hipStream_t s)
 {
@@ -299,19 +361,28 @@ void ell_dict_try_build(const cgh_matrix *m, hipStream_t s)
     std::sort(offs.begin(), offs.end());
     const int count = (int)offs.size();
     offs.resize(256, 0);
+    // narrow rows: one byte per entry, slot-major; wide rows (more load instructions than bytes are worth): 4 slots
+    // of a row per 32-bit word.  CGH_ELL_DICT=1 / 2 forces a layout.
+    const int mode = enabled == 2 ? 2 : (enabled == 1 && getenv("CGH_ELL_DICT") ? 1 : (m->K > 8 ? 2 : 1));
+    const size_t code_bytes = mode == 2 ? (size_t)((m->K + 3) / 4) * (size_t)m->n * 4 : (size_t)total;
     m->off_tab = (int *)cgh_alloc(sizeof(int) * 256);
-    m->cols8 = (unsigned char *)cgh_alloc((size_t)total);
+    m->cols8 = (unsigned char *)cgh_alloc(code_bytes);
     if (!m->off_tab || !m->cols8 || cgh_h2d(m->off_tab, offs.data(), sizeof(int) * 256) != CGH_OK) {
         cgh_ell_dict_free(m);
         return;
     }
-    hipLaunchKernelGGL(dict_encode, dim3(grid), dim3(256), 0, s, total, m->n, (const int *)m->cols, (const int *)m->off_tab, count,
-                       m->cols8);
+    if (mode == 2)
+        hipLaunchKernelGGL(dict_encode_packed, dim3(grid), dim3(256), 0, s, m->n, m->K, (const int *)m->cols, (const int *)m->off_tab,
+                           count, reinterpret_cast<unsigned *>(m->cols8));
+    else
+        hipLaunchKernelGGL(dict_encode, dim3(grid), dim3(256), 0, s, total, m->n, (const int *)m->cols, (const int *)m->off_tab, count,
+                           m->cols8);
     if (hipGetLastError() != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
         cgh_ell_dict_free(m);
         return;
     }
     m->n_offsets = count;
+    m->dict_mode = mode;
     m->dict_state = 1;
 }
 
@@ -387,12 +458,19 @@ int cgh_launch_spmv_ell_range2(const cgh_matrix *m, const double *x, double *y, 
             if (cap == hipStreamCaptureStatusNone) ell_dict_try_build(m, s);
         }
         if (m->dict_state == 1) {
-            if (dot_partials)
-                launch_r2<true, VAR_DEFAULT, true>(m->K, grid, s, m->n, m->diag, m->vals, m->cols8, m->off_tab, x, y, dot_partials,
-                                                   done, rb, re, rb2, re2);
+            if (m->dict_mode == 2) {
+                if (dot_partials)
+                    launch_r2<true, VAR_DEFAULT, 2>(m->K, grid, s, m->n, m->diag, m->vals, m->cols8, m->off_tab, x, y, dot_partials,
+                                                    done, rb, re, rb2, re2);
+                else
+                    launch_r2<false, VAR_DEFAULT, 2>(m->K, grid, s, m->n, m->diag, m->vals, m->cols8, m->off_tab, x, y, nullptr, done,
+                                                     rb, re, rb2, re2);
+            } else if (dot_partials)
+                launch_r2<true, VAR_DEFAULT, 1>(m->K, grid, s, m->n, m->diag, m->vals, m->cols8, m->off_tab, x, y, dot_partials,
+                                                done, rb, re, rb2, re2);
             else
-                launch_r2<false, VAR_DEFAULT, true>(m->K, grid, s, m->n, m->diag, m->vals, m->cols8, m->off_tab, x, y, nullptr, done,
-                                                    rb, re, rb2, re2);
+                launch_r2<false, VAR_DEFAULT, 1>(m->K, grid, s, m->n, m->diag, m->vals, m->cols8, m->off_tab, x, y, nullptr, done,
+                                                 rb, re, rb2, re2);
             CGH_HIP(hipGetLastError());
             return CGH_OK;
         }

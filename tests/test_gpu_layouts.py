@@ -149,16 +149,17 @@ def test_dictionary_coded_columns_same_bits(cga, monkeypatch, case):
     xh = rng.standard_normal(n)
     x = cga.DeviceVector.from_host(xh); y = cga.DeviceVector(n)
     out = {}
-    for flag in ("0", "1"):
+    for flag in ("0", "1", "2"):      # int32 columns / one byte per entry / 4 slots of a row per 32-bit word
         monkeypatch.setenv("CGH_ELL_DICT", flag)
         A = cga.Matrix.from_coo(n, s["diag"], s["upper"], s["rows"], s["cols"], cga.LAYOUT_ELL)
         assert A.dict_offsets == -1
         A.spmv(x, y)
         out[flag] = (y.to_host(), A.dict_offsets)
     want = O.mv_coo(n, s["diag"], s["upper"], s["rows"], s["cols"], xh)
-    assert np.array_equal(bits(out["0"][0]), bits(want)) and np.array_equal(bits(out["1"][0]), bits(want))
+    for flag in ("0", "1", "2"):
+        assert np.array_equal(bits(out[flag][0]), bits(want)), flag
     assert out["0"][1] == 0
     if case in ("poisson7", "poisson27", "banded_random"):
-        assert 0 < out["1"][1] <= 255
+        assert 0 < out["1"][1] <= 255 and out["2"][1] == out["1"][1]
     elif case == "unstructured":
-        assert out["1"][1] == 0
+        assert out["1"][1] == 0 and out["2"][1] == 0
