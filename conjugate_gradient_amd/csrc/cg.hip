@@ -6,9 +6,10 @@
 // moving the fused minimum 12K+96 B/row:
 //
 //   K1  spmv(+dot)   Ap = A p, per-workgroup partial of p.Ap                 (spmv_*.hip)
-//   K2  update_xr    alpha = rr/(p.Ap) from the partials (every workgroup, same order);
-//                    x += alpha p; r -= alpha Ap; partials of r.r and |r|_1
-//   K3  update_p     rr' and l1 from the partials; convergence test; beta = rr'/rr; p = r + beta p
+//   K2  update_r     alpha = rr/(p.Ap) from the partials (every workgroup, same order);
+//                    r -= alpha Ap; partials of r.r and |r|_1
+//   K3  update_xp    x += alpha p; rr' and l1 from the partials; convergence test; beta = rr'/rr; p = r + beta p
+//                    (x is advanced here, not in K2: K3 reads p anyway, which saves one sweep over p per iteration)
 //
 // Scalars never visit the host: each consumer kernel re-derives them from the producer's
 // partials in its prologue (<= 2048 doubles, L2-resident), workgroup 0 records them in the
@@ -291,27 +292,27 @@ static int enqueue_iterations(cgh_solver *sv, int count, int time_kernels, bool 
         if (time_kernels) CGH_HIP(hipEventRecord(sv->kev.back(), s));
         if (sv->precond == CGH_PRECOND_JACOBI) {
             const double *dg = sv->m->diag;
-            hipLaunchKernelGGL(pcg_update_xr, dim3(vg), dim3(CGH_BLOCK), 0, s, n, d_x, (const double *)dp, dr, (const double *)dAp, dg,
-                               (const double *)dA, gridA, dB, dh, iter, (const int *)dd);
-            hipLaunchKernelGGL(pcg_update_p, dim3(vg), dim3(CGH_BLOCK), 0, s, n, (const double *)dr, dp, dg, (const double *)dB, vg,
-                               dh, iter, tol, dd);
+            hipLaunchKernelGGL(pcg_update_r, dim3(vg), dim3(CGH_BLOCK), 0, s, n, dr, (const double *)dAp, dg, (const double *)dA,
+                               gridA, dB, dh, iter, (const int *)dd);
+            hipLaunchKernelGGL(pcg_update_xp, dim3(vg), dim3(CGH_BLOCK), 0, s, n, d_x, (const double *)dr, dp, dg,
+                               (const double *)dB, vg, dh, iter, tol, dd);
         } else if (sv->strict) {
             rc = strict_sums(sv, dp, dAp, nullptr, 1, iter, s);
             if (rc) return rc;
-            hipLaunchKernelGGL((cg_update_xr<1, 3>), dim3(vg), dim3(CGH_BLOCK), 0, s, n, d_x, (const double *)dp, dr,
-                               (const double *)dAp, (const double *)dA, gridA, dB, dh, iter, (const int *)dd, rev2, (const double *)nullptr);
+            hipLaunchKernelGGL((cg_update_r<1, 3>), dim3(vg), dim3(CGH_BLOCK), 0, s, n, dr, (const double *)dAp,
+                               (const double *)dA, gridA, dB, dh, iter, (const int *)dd, rev2, (const double *)nullptr);
             rc = strict_sums(sv, dr, dr, dr, 2, iter, s);
             if (rc) return rc;
-            hipLaunchKernelGGL((cg_update_p<1, 3>), dim3(vg), dim3(CGH_BLOCK), 0, s, n, (const double *)dr, dp,
+            hipLaunchKernelGGL((cg_update_xp<1, 3>), dim3(vg), dim3(CGH_BLOCK), 0, s, n, d_x, (const double *)dr, dp,
                                (const double *)dB, vg, dh, iter, tol, dd, rev1, (const double *)nullptr);
         } else {
             static const int vv = getenv("CGH_VEC_VARIANT") ? atoi(getenv("CGH_VEC_VARIANT")) & 15 : 3;
 #define CGH_VEC_VAR(V)                                                                                                 \
     case V:                                                                                                            \
-        hipLaunchKernelGGL((cg_update_xr<0, V>), dim3(vg), dim3(CGH_BLOCK), 0, s, n, d_x, (const double *)dp, dr,  \
-                           (const double *)dAp, (const double *)dA, gridA, dB, dh, iter, (const int *)dd, rev2, (const double *)nullptr);             \
-        hipLaunchKernelGGL((cg_update_p<0, V>), dim3(vg), dim3(CGH_BLOCK), 0, s, n, (const double *)dr, dp,        \
-                           (const double *)dB, vg, dh, iter, tol, dd, rev1, (const double *)nullptr);                                                 \
+        hipLaunchKernelGGL((cg_update_r<0, V>), dim3(vg), dim3(CGH_BLOCK), 0, s, n, dr, (const double *)dAp,       \
+                           (const double *)dA, gridA, dB, dh, iter, (const int *)dd, rev2, (const double *)nullptr);   \
+        hipLaunchKernelGGL((cg_update_xp<0, V>), dim3(vg), dim3(CGH_BLOCK), 0, s, n, d_x, (const double *)dr, dp,  \
+                           (const double *)dB, vg, dh, iter, tol, dd, rev1, (const double *)nullptr);                  \
         break;
             switch (vv) {
                 CGH_VEC_VAR(0)

@@ -14,7 +14,7 @@ typedef double d2_t __attribute__((ext_vector_type(2)));
 // Streaming accesses: every vector here is far larger than L2 and touched once per kernel, so loads and
 // stores are non-temporal (measured +15 % on the SpMV's y store, profiles/).  VV bit0 = nt loads, bit1 = nt stores
 // of x, bit2 = nt stores of r, bit3 = nt stores of p.  Shipped: 3 -- x is not touched again until the next iteration,
-// while r (re-read by cg_update_p) and p (re-read by the SpMV) are left to the caches: 0.4713 vs 0.4787 ms/iteration
+// while r (re-read by cg_update_xp) and p (re-read by the SpMV) are left to the caches: 0.4713 vs 0.4787 ms/iteration
 // with everything non-temporal (256^3, MI355X).
 template <int VV>
 __device__ __forceinline__ double2 ld2(const double *p, int64_t k)
@@ -76,22 +76,25 @@ __global__ __launch_bounds__(CGH_BLOCK) void cg_finish_init(const double *__rest
     }
 }
 
-// K2.  VEC2: n even and 16-B aligned vectors.
+// K2.  r -= alpha Ap; partials of r.r and |r|_1.  (x += alpha p is done by K3, which reads p anyway: one sweep over p
+// less per iteration, same arithmetic, same bits.)
 // MODE 0: alpha from this GPU's p.Ap partials; 1: alpha already in the history (strict sums); 2: p.Ap reduced
 // over all ranks waits in gs[0] (multi-GPU).
 template <int MODE, int VV>
-__global__ __launch_bounds__(CGH_BLOCK) void cg_update_xr(int64_t n, double *__restrict__ x, const double *__restrict__ p,
-                                                         double *__restrict__ r, const double *__restrict__ Ap,
-                                                         const double *__restrict__ pAp_partials, int pAp_count,
-                                                         double *__restrict__ out_partials, double *hist, int iter,
-                                                         const int *__restrict__ done, int rev,
-                                                         const double *__restrict__ gs)
+__global__ __launch_bounds__(CGH_BLOCK) void cg_update_r(int64_t n, double *__restrict__ r, const double *__restrict__ Ap,
+                                                        const double *__restrict__ pAp_partials, int pAp_count,
+                                                        double *__restrict__ out_partials, double *hist, int iter,
+                                                        const int *__restrict__ done, int rev, const double *__restrict__ gs)
 {
     constexpr bool STRICT = MODE == 1;
     __shared__ double lds[4];
-    if (*done != 0) return;
-    // iter == 0: take the iteration number from the device (done[2] = last iteration finished by cg_update_p), so that
-    // identical launches can be replayed from a HIP graph; done[1] tells cg_update_p which iteration this is
+    if (*done != 0) {
+        // frozen.  A replayed (graph) launch tells the cg_update_xp behind it that there is no iteration in flight.
+        if (iter == 0 && blockIdx.x == 0 && threadIdx.x == 0) const_cast<int *>(done)[1] = 0;
+        return;
+    }
+    // iter == 0: take the iteration number from the device (done[2] = last iteration finished by cg_update_xp), so that
+    // identical launches can be replayed from a HIP graph; done[1] tells cg_update_xp which iteration this is
     if (iter == 0) iter = done[2] + 1;
     if (blockIdx.x == 0 && threadIdx.x == 0) const_cast<int *>(done)[1] = iter;
     double alpha;
@@ -112,14 +115,10 @@ __global__ __launch_bounds__(CGH_BLOCK) void cg_update_xr(int64_t n, double *__r
     for (int64_t cc = blockIdx.x; cc < chunks; cc += gridDim.x) {
         const int64_t k = (rev ? chunks - 1 - cc : cc) * CGH_BLOCK + threadIdx.x;
         if (k >= pairs) continue;
-        const double2 xv = ld2<VV>(x, k);
-        const double2 pv = ld2<VV>(p, k);
         const double2 rv = ld2<VV>(r, k);
         const double2 av = ld2<VV>(Ap, k);
-        // reference vec_axpy: out = a + alpha*b (vec.c:88-94), called with alpha and -alpha (cg.c:467,469)
-        const double2 xn = make_double2(madd_rn(xv.x, alpha, pv.x), madd_rn(xv.y, alpha, pv.y));
+        // reference vec_axpy: out = a + alpha*b (vec.c:88-94), called with -alpha (cg.c:469)
         const double2 rn = make_double2(madd_rn(rv.x, nalpha, av.x), madd_rn(rv.y, nalpha, av.y));
-        st2<(VV & 2) != 0>(x, k, xn.x, xn.y);
         st2<(VV & 4) != 0>(r, k, rn.x, rn.y);
         if constexpr (!STRICT) {
             rr += rn.x * rn.x + rn.y * rn.y;
@@ -128,9 +127,7 @@ __global__ __launch_bounds__(CGH_BLOCK) void cg_update_xr(int64_t n, double *__r
     }
     if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
         const int64_t i = n - 1;
-        const double  xn = madd_rn(x[i], alpha, p[i]);
         const double  rn = madd_rn(r[i], nalpha, Ap[i]);
-        x[i] = xn;
         r[i] = rn;
         if constexpr (!STRICT) {
             rr += rn * rn;
@@ -147,18 +144,25 @@ __global__ __launch_bounds__(CGH_BLOCK) void cg_update_xr(int64_t n, double *__r
     }
 }
 
-// K3.
+// K3.  x += alpha p (alpha of this iteration, from the history); then the convergence test, beta, p = r + beta p.
 template <int MODE, int VV>
-__global__ __launch_bounds__(CGH_BLOCK) void cg_update_p(int64_t n, const double *__restrict__ r, double *__restrict__ p,
-                                                        const double *__restrict__ partials, int count, double *hist,
-                                                        int iter, double tol, int *done, int rev,
-                                                        const double *__restrict__ gs)
+__global__ __launch_bounds__(CGH_BLOCK) void cg_update_xp(int64_t n, double *__restrict__ x, const double *__restrict__ r,
+                                                         double *__restrict__ p, const double *__restrict__ partials, int count,
+                                                         double *hist, int iter, double tol, int *done, int rev,
+                                                         const double *__restrict__ gs)
 {
     constexpr bool STRICT = MODE == 1;
     __shared__ double lds[4];
-    if (*done != 0) return;
-    if (iter == 0) iter = done[1];
+    if (iter == 0) {
+        iter = done[1];
+        if (iter == 0) return;  // replayed launch behind a frozen cg_update_r
+    }
+    // The flag may already name THIS iteration: set by the strict sums just before this launch, or by workgroup 0 of
+    // this very launch (below) -- either way the converging iteration still owes its x update.
+    const int frozen_at = *done;
+    if (frozen_at != 0 && frozen_at != iter) return;
     if (blockIdx.x == 0 && threadIdx.x == 0) done[2] = iter;
+    const double alpha = hist[(size_t)iter * HIST + 2];
     double beta;
     bool   conv;
     if constexpr (MODE == 1) {
@@ -182,23 +186,36 @@ __global__ __launch_bounds__(CGH_BLOCK) void cg_update_p(int64_t n, const double
             hist[(size_t)iter * HIST + 3] = conv ? NAN : beta;
         }
     }
-    if (conv) {
-        // the reference returns before touching p (cg.c:475-485); later iterations see the flag and do nothing.
-        // Every workgroup reaches the same verdict from the same partials; workgroup 0 publishes it, and no
-        // workgroup of THIS launch reads it back.
-        if (STRICT == false && blockIdx.x == 0 && threadIdx.x == 0) *done = iter;
-        return;
-    }
     const int64_t pairs = n >> 1;
     const int64_t chunks = (pairs + CGH_BLOCK - 1) / CGH_BLOCK;
+    if (conv) {
+        // the reference updates x, then returns before touching p (cg.c:467-485); later iterations see the flag and do
+        // nothing.  Every workgroup reaches the same verdict from the same partials; workgroup 0 publishes it, and no
+        // workgroup of THIS launch reads it back.
+        if (STRICT == false && blockIdx.x == 0 && threadIdx.x == 0) *done = iter;
+        for (int64_t cc = blockIdx.x; cc < chunks; cc += gridDim.x) {
+            const int64_t k = cc * CGH_BLOCK + threadIdx.x;
+            if (k >= pairs) continue;
+            const double2 xv = ld2<VV>(x, k), pv = ld2<VV>(p, k);
+            st2<(VV & 2) != 0>(x, k, madd_rn(xv.x, alpha, pv.x), madd_rn(xv.y, alpha, pv.y));
+        }
+        if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) x[n - 1] = madd_rn(x[n - 1], alpha, p[n - 1]);
+        return;
+    }
     for (int64_t cc = blockIdx.x; cc < chunks; cc += gridDim.x) {
         const int64_t k = (rev ? chunks - 1 - cc : cc) * CGH_BLOCK + threadIdx.x;
         if (k >= pairs) continue;
+        const double2 xv = ld2<VV>(x, k);
         const double2 rv = ld2<VV>(r, k);
         const double2 pv = ld2<VV>(p, k);
+        // reference vec_axpy: out = a + alpha*b (vec.c:88-94): x += alpha p (cg.c:467), p = r + beta p (cg.c:489)
+        st2<(VV & 2) != 0>(x, k, madd_rn(xv.x, alpha, pv.x), madd_rn(xv.y, alpha, pv.y));
         st2<(VV & 8) != 0>(p, k, madd_rn(rv.x, beta, pv.x), madd_rn(rv.y, beta, pv.y));
     }
-    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) p[n - 1] = madd_rn(r[n - 1], beta, p[n - 1]);
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+        x[n - 1] = madd_rn(x[n - 1], alpha, p[n - 1]);
+        p[n - 1] = madd_rn(r[n - 1], beta, p[n - 1]);
+    }
 }
 
 // ---------------------------------------------------------------- Jacobi-preconditioned variant
@@ -228,14 +245,16 @@ __global__ __launch_bounds__(CGH_BLOCK) void pcg_init_rp(int64_t n, const double
     }
 }
 
-__global__ __launch_bounds__(CGH_BLOCK) void pcg_update_xr(int64_t n, double *__restrict__ x, const double *__restrict__ p,
-                                                          double *__restrict__ r, const double *__restrict__ Ap,
-                                                          const double *__restrict__ dg, const double *__restrict__ pAp_partials,
-                                                          int pAp_count, double *__restrict__ out_partials, double *hist, int iter,
-                                                          const int *__restrict__ done)
+__global__ __launch_bounds__(CGH_BLOCK) void pcg_update_r(int64_t n, double *__restrict__ r, const double *__restrict__ Ap,
+                                                         const double *__restrict__ dg, const double *__restrict__ pAp_partials,
+                                                         int pAp_count, double *__restrict__ out_partials, double *hist, int iter,
+                                                         const int *__restrict__ done)
 {
     __shared__ double lds[4];
-    if (*done != 0) return;
+    if (*done != 0) {
+        if (iter == 0 && blockIdx.x == 0 && threadIdx.x == 0) const_cast<int *>(done)[1] = 0;
+        return;
+    }
     if (iter == 0) iter = done[2] + 1;
     if (blockIdx.x == 0 && threadIdx.x == 0) const_cast<int *>(done)[1] = iter;
     const double pAp = block_sum_partials(pAp_partials, pAp_count, 1, lds);
@@ -245,18 +264,15 @@ __global__ __launch_bounds__(CGH_BLOCK) void pcg_update_xr(int64_t n, double *__
     double       rz = 0.0, l1 = 0.0;
     const int64_t pairs = n >> 1;
     for (int64_t k = (int64_t)blockIdx.x * CGH_BLOCK + threadIdx.x; k < pairs; k += (int64_t)gridDim.x * CGH_BLOCK) {
-        const double2 xv = ld2<1>(x, k), pv = ld2<1>(p, k), rv = ld2<1>(r, k), av = ld2<1>(Ap, k), dv = ld2<1>(dg, k);
-        const double2 xn = make_double2(madd_rn(xv.x, alpha, pv.x), madd_rn(xv.y, alpha, pv.y));
+        const double2 rv = ld2<1>(r, k), av = ld2<1>(Ap, k), dv = ld2<1>(dg, k);
         const double2 rn = make_double2(madd_rn(rv.x, nalpha, av.x), madd_rn(rv.y, nalpha, av.y));
-        st2<true>(x, k, xn.x, xn.y);
         st2<false>(r, k, rn.x, rn.y);
         rz += rn.x * (rn.x / dv.x) + rn.y * (rn.y / dv.y);
         l1 += fabs(rn.x) + fabs(rn.y);
     }
     if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
         const int64_t i = n - 1;
-        const double  xn = madd_rn(x[i], alpha, p[i]), rn = madd_rn(r[i], nalpha, Ap[i]);
-        x[i] = xn;
+        const double  rn = madd_rn(r[i], nalpha, Ap[i]);
         r[i] = rn;
         rz += rn * (rn / dg[i]);
         l1 += fabs(rn);
@@ -269,14 +285,20 @@ __global__ __launch_bounds__(CGH_BLOCK) void pcg_update_xr(int64_t n, double *__
     }
 }
 
-__global__ __launch_bounds__(CGH_BLOCK) void pcg_update_p(int64_t n, const double *__restrict__ r, double *__restrict__ p,
-                                                         const double *__restrict__ dg, const double *__restrict__ partials,
-                                                         int count, double *hist, int iter, double tol, int *done)
+__global__ __launch_bounds__(CGH_BLOCK) void pcg_update_xp(int64_t n, double *__restrict__ x, const double *__restrict__ r,
+                                                          double *__restrict__ p, const double *__restrict__ dg,
+                                                          const double *__restrict__ partials, int count, double *hist, int iter,
+                                                          double tol, int *done)
 {
     __shared__ double lds[4];
-    if (*done != 0) return;
-    if (iter == 0) iter = done[1];
+    if (iter == 0) {
+        iter = done[1];
+        if (iter == 0) return;
+    }
+    const int frozen_at = *done;
+    if (frozen_at != 0 && frozen_at != iter) return;
     if (blockIdx.x == 0 && threadIdx.x == 0) done[2] = iter;
+    const double alpha = hist[(size_t)iter * HIST + 2];
     const double rz = block_sum_partials(partials, count, 2, lds);
     const double l1 = block_sum_partials(partials + 1, count, 2, lds);
     const double res = l1 / 2.0;
@@ -286,17 +308,22 @@ __global__ __launch_bounds__(CGH_BLOCK) void pcg_update_p(int64_t n, const doubl
         hist[(size_t)iter * HIST + 0] = res;
         hist[(size_t)iter * HIST + 1] = rz;
         hist[(size_t)iter * HIST + 3] = conv ? NAN : beta;
-    }
-    if (conv) {
-        if (blockIdx.x == 0 && threadIdx.x == 0) *done = iter;
-        return;
+        if (conv) *done = iter;
     }
     const int64_t pairs = n >> 1;
     for (int64_t k = (int64_t)blockIdx.x * CGH_BLOCK + threadIdx.x; k < pairs; k += (int64_t)gridDim.x * CGH_BLOCK) {
-        const double2 rv = ld2<1>(r, k), pv = ld2<1>(p, k), dv = ld2<1>(dg, k);
-        st2<false>(p, k, madd_rn(rv.x / dv.x, beta, pv.x), madd_rn(rv.y / dv.y, beta, pv.y));
+        const double2 xv = ld2<1>(x, k), pv = ld2<1>(p, k);
+        st2<true>(x, k, madd_rn(xv.x, alpha, pv.x), madd_rn(xv.y, alpha, pv.y));
+        if (!conv) {
+            const double2 rv = ld2<1>(r, k), dv = ld2<1>(dg, k);
+            st2<false>(p, k, madd_rn(rv.x / dv.x, beta, pv.x), madd_rn(rv.y / dv.y, beta, pv.y));
+        }
     }
-    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) p[n - 1] = madd_rn(r[n - 1] / dg[n - 1], beta, p[n - 1]);
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+        const int64_t i = n - 1;
+        x[i] = madd_rn(x[i], alpha, p[i]);
+        if (!conv) p[i] = madd_rn(r[i] / dg[i], beta, p[i]);
+    }
 }
 
 // ---------------------------------------------------------------- strict (sequential-order) sums
@@ -334,7 +361,7 @@ __global__ __launch_bounds__(CGH_BLOCK) void seq_sums(int64_t n, const double *_
     __shared__ __attribute__((aligned(16))) double prod[SEQ_CHUNK];
     __shared__ __attribute__((aligned(16))) double absv[SEQ_CHUNK];
     if (done != nullptr && mode != 3 && mode != 0 && *done != 0) return;
-    if (iter == 0 && mode == 1) iter = done[2] + 1;   // before cg_update_xr of this iteration
+    if (iter == 0 && mode == 1) iter = done[2] + 1;   // before cg_update_r of this iteration
     if (iter == 0 && mode == 2) iter = done[1];       // after it
     double s_dot = 0.0, s_l1 = 0.0;
     for (int64_t base = 0; base < n; base += SEQ_CHUNK) {

@@ -6,8 +6,8 @@
 //        ncclGroup{ ncclSend to / ncclRecv from each neighbour, straight into the halo tail of p } ; record(halo)
 //     s: SpMV of the interior rows [a,b) (they reference no halo column)            -- overlaps the exchange
 //        wait(halo) ; SpMV of the boundary rows [0,a) and [b,n_loc)
-//        local p.Ap -> ncclAllReduce(1 double) ; x,r update (+ local r.r, |r|_1) -> ncclAllReduce(2 doubles) ;
-//        p update, convergence flag (identical on every rank: all see the same reduced scalars)
+//        local p.Ap -> ncclAllReduce(1 double) ; r update (+ local r.r, |r|_1) -> ncclAllReduce(2 doubles) ;
+//        x and p update, convergence flag (identical on every rank: all see the same reduced scalars)
 // Scalars stay on the device; the host only queues work and polls the flag every `check_every` iterations.
 //
 // xGMI is point-to-point (a dedicated link per GPU pair), so the neighbour exchange is plain send/recv pairs,
@@ -570,12 +570,11 @@ int cgh_dist_iterate(cgh_dist *d, int count, int time_kernels)
         if (time_kernels) CGH_HIP(hipEventRecord(d->kev.back(), s));
         hipLaunchKernelGGL(reduce_local<1>, dim3(1), dim3(CGH_BLOCK), 0, s, (const double *)d->partA, cnt, d->gs_local);
         CGH_NCCL(g_rccl.AllReduce(d->gs_local, d->gs, 1, ncclDouble, ncclSum, g_rccl.comm, s));
-        hipLaunchKernelGGL((cg_update_xr<2, 3>), dim3(d->vgrid), dim3(CGH_BLOCK), 0, s, nl, d->x, (const double *)d->p, d->r,
-                           (const double *)d->Ap, (const double *)nullptr, 0, d->partB, d->hist, iter, (const int *)d->done, 0,
-                           (const double *)d->gs);
+        hipLaunchKernelGGL((cg_update_r<2, 3>), dim3(d->vgrid), dim3(CGH_BLOCK), 0, s, nl, d->r, (const double *)d->Ap,
+                           (const double *)nullptr, 0, d->partB, d->hist, iter, (const int *)d->done, 0, (const double *)d->gs);
         hipLaunchKernelGGL(reduce_local<2>, dim3(2), dim3(CGH_BLOCK), 0, s, (const double *)d->partB, d->vgrid, d->gs_local + 1);
         CGH_NCCL(g_rccl.AllReduce(d->gs_local + 1, d->gs + 1, 2, ncclDouble, ncclSum, g_rccl.comm, s));
-        hipLaunchKernelGGL((cg_update_p<2, 3>), dim3(d->vgrid), dim3(CGH_BLOCK), 0, s, nl, (const double *)d->r, d->p,
+        hipLaunchKernelGGL((cg_update_xp<2, 3>), dim3(d->vgrid), dim3(CGH_BLOCK), 0, s, nl, d->x, (const double *)d->r, d->p,
                            (const double *)nullptr, 0, d->hist, iter, d->tol, d->done, 0, (const double *)d->gs);
         CGH_HIP(hipGetLastError());
     }
@@ -717,15 +716,14 @@ int cgh_dist_group_iterate(cgh_dist **R, int G, int count)
         for (int g = 0; g < G; ++g) {
             cgh_dist *d = R[g];
             const int iter = ++d->queued;
-            hipLaunchKernelGGL((cg_update_xr<2, 3>), dim3(d->vgrid), dim3(CGH_BLOCK), 0, s, d->n_loc, d->x, (const double *)d->p, d->r,
-                               (const double *)d->Ap, (const double *)nullptr, 0, d->partB, d->hist, iter, (const int *)d->done, 0,
-                               (const double *)d->gs);
+            hipLaunchKernelGGL((cg_update_r<2, 3>), dim3(d->vgrid), dim3(CGH_BLOCK), 0, s, d->n_loc, d->r, (const double *)d->Ap,
+                               (const double *)nullptr, 0, d->partB, d->hist, iter, (const int *)d->done, 0, (const double *)d->gs);
             hipLaunchKernelGGL(reduce_local<2>, dim3(2), dim3(CGH_BLOCK), 0, s, (const double *)d->partB, d->vgrid, d->gs_local + 1);
         }
         hipLaunchKernelGGL(group_allreduce, dim3(1), dim3(64), 0, s, G, (double *const *)d0->d_locals, (double *const *)d0->d_outs, 1, 2);
         for (int g = 0; g < G; ++g) {
             cgh_dist *d = R[g];
-            hipLaunchKernelGGL((cg_update_p<2, 3>), dim3(d->vgrid), dim3(CGH_BLOCK), 0, s, d->n_loc, (const double *)d->r, d->p,
+            hipLaunchKernelGGL((cg_update_xp<2, 3>), dim3(d->vgrid), dim3(CGH_BLOCK), 0, s, d->n_loc, d->x, (const double *)d->r, d->p,
                                (const double *)nullptr, 0, d->hist, d->queued, d->tol, d->done, 0, (const double *)d->gs);
         }
         CGH_HIP(hipGetLastError());
