@@ -29,8 +29,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-# libcg_hip first (binds /opt/rocm's HIP runtime); torch -- imported only for the multi-rank
-# rendezvous -- then finds libamdhip64.so.7 already loaded.
+# torch is never imported: the multi-rank leg (bench_dist.py) bootstraps RCCL through a file in /tmp and uses the
+# library's own communicator for its barriers, so the process holds one HIP runtime and one RCCL (/opt/rocm's).
 import conjugate_gradient_amd as cga  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
@@ -107,6 +107,7 @@ def main():
     ap.add_argument("--workload", default="p7_256", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dist", action="store_true", help="use the multi-rank code path even with one rank (testing)")
+    ap.add_argument("--no-config4", action="store_true", help="multi-rank runs: skip the extra 27-point 512^3 leg")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -122,7 +123,7 @@ def main():
     cga.init(local_rank)
 
     if world > 1 or args.dist:
-        cga.check(cga.lib().cgh_comm_preload(), "cgh_comm_preload")   # /opt/rocm's RCCL, before torch brings its own copy
+        cga.check(cga.lib().cgh_comm_preload(), "cgh_comm_preload")   # /opt/rocm's RCCL
         import bench_dist
         return bench_dist.run(args, rank, world, local_rank, (nx, ny, nz, points), SEED)
 

@@ -1,8 +1,16 @@
 """bench_dist.py -- the N>1 leg of bench.py: one rank per GPU (torch.distributed.run), the benchmark matrix
 row-block (z-slab) partitioned over the ranks, halo exchange + all-reduces over RCCL inside libcg_hip.
-torch.distributed (gloo) is used only for the rendezvous: broadcast of the ncclUniqueIds, barriers, max-over-ranks."""
+The launcher (python -m torch.distributed.run) only provides RANK / WORLD_SIZE / LOCAL_RANK: the ranks of the one node
+hand the ncclUniqueIds over through a file in /tmp named after the launcher's pid, and every later exchange (barriers,
+max-over-ranks) is an RCCL all-reduce of the library's own communicator.  torch is not imported here: its wheel brings
+its own copies of the HIP runtime and RCCL, and a process that holds both sets aborts at exit.
+
+The JSON line's `value` is the workload bench.py was asked for (default p7_256: the 16.7M-row matrix of BASELINE's
+north-star target split over the N GPUs, strong scaling).  For the default workload the line also carries
+`config4`: BASELINE config 4 (27-point 512^3, 134M rows, 42 GB of ELL) partitioned over the same N GPUs."""
 import json
 import os
+import sys
 import time
 
 import numpy as np
@@ -12,61 +20,118 @@ import conjugate_gradient_amd as cga
 HBM_PEAK_GBS = 8000.0
 
 
-def run(args, rank, world, local_rank, shape, seed):
-    import torch
-    import torch.distributed as dist
+def exchange_unique_id(rank, world):
+    """rank 0 creates the 256-byte id and publishes it atomically; the other ranks of the node wait for the file"""
+    path = "/tmp/cgh_uid_%d_%s" % (os.getppid(), os.environ.get("MASTER_PORT", "0"))
+    if rank == 0:
+        ident = cga.comm_unique_id()
+        with open(path + ".tmp", "wb") as f:
+            f.write(ident)
+        os.replace(path + ".tmp", path)
+        return ident, path
+    deadline = time.time() + 300.0
+    while time.time() < deadline:
+        try:
+            with open(path, "rb") as f:
+                ident = f.read()
+            if len(ident) == 256:
+                return ident, path
+        except FileNotFoundError:
+            pass
+        time.sleep(0.02)
+    raise SystemExit("bench_dist: rank %d never saw %s" % (rank, path))
 
+
+def barrier():
+    cga.comm_allreduce([0.0], "sum")
+
+
+def measure(rank, world, shape, seed, steps, warmup):
+    """One partitioned workload: generate this rank's z-slab, warm up, time `steps` iterations (barrier + device sync on
+    both sides, MAX over ranks).  Returns a dict on every rank, or None if some rank could not set the problem up."""
     nx, ny, nz, points = shape
-    dist.init_process_group("gloo", rank=rank, world_size=world)   # MASTER_ADDR/PORT from the launcher's env
-    ids = [cga.comm_unique_id() if rank == 0 else None]
-    dist.broadcast_object_list(ids, src=0)
-    cga.comm_init(world, rank, ids[0])
-
     nl = nx * ny * (nz * (rank + 1) // world - nz * rank // world)
-    b = cga.DeviceVector(nl)
-    x = cga.DeviceVector(nl)
-    D = cga.DistRank.poisson(nx, ny, nz, points, seed, world, rank, b)
-    cap = args.warmup + args.steps + 1
+    ok = 1
+    try:
+        b = cga.DeviceVector(nl)
+        x = cga.DeviceVector(nl)
+        D = cga.DistRank.poisson(nx, ny, nz, points, seed, world, rank, b)
+    except Exception as e:  # noqa: BLE001  (reported; the collective part below is skipped on every rank)
+        print("[rank %d] set-up of %dx%dx%d/%d-point failed: %s" % (rank, nx, ny, nz, points, e), flush=True)
+        ok = 0
+    if cga.comm_allreduce([ok], "min")[0] == 0:
+        return None
+    cap = warmup + steps + 1
     D.start(b, x, -1.0, cap)                    # tol < 0: never converges, every step does full work
-    D.iterate(args.warmup, 0)
+    D.iterate(warmup, 0)
     cga.check(cga.lib().cgh_sync())
-    dist.barrier()
+    barrier()
     t0 = time.perf_counter()
-    D.iterate(args.steps, 1)                    # timed region: exactly K iterations
+    D.iterate(steps, 1)                         # timed region: exactly K iterations
     cga.check(cga.lib().cgh_sync())
-    dist.barrier()
+    barrier()
     dt = time.perf_counter() - t0
     spmv_ms = D.spmv_ms()
-    t = torch.tensor([dt, spmv_ms], dtype=torch.float64)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)     # slowest rank
-    dt, spmv_ms = t.tolist()
-    nnz = torch.tensor([D.nnz_offdiag], dtype=torch.int64)
-    dist.all_reduce(nnz)
+    dt, spmv_ms = cga.comm_allreduce([dt, spmv_ms], "max")      # slowest rank
+    nnz_total = cga.comm_allreduce([float(D.nnz_offdiag)], "sum")[0]   # exact: far below 2^53
     hist = D.history(0, cap)
     assert np.all(np.isfinite(hist[1:, 0])), "non-finite residual: the iteration did not run"
+    n = nx * ny * nz
+    nnz_off = int(nnz_total)
+    alg_spmv = 12 * nnz_off + 24 * n
+    D.free()
+    return {"n": n, "nnz_off": nnz_off, "alg_spmv": alg_spmv, "dt": dt, "spmv_ms": spmv_ms, "steps": steps,
+            "ms_step": dt / steps * 1e3, "achieved": alg_spmv / (spmv_ms * 1e-3) / 1e9,
+            "res": [float(hist[0, 0]), float(hist[-1, 0])]}
+
+
+def run(args, rank, world, local_rank, shape, seed):
+    nx, ny, nz, points = shape
+    ident, path = exchange_unique_id(rank, world)
+    # RCCL prints its version banner on stdout when the communicator comes up; stdout is for the one JSON line
+    sys.stdout.flush()
+    saved = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        cga.comm_init(world, rank, ident)
+        barrier()
+    finally:
+        os.dup2(saved, 1)
+        os.close(saved)
     if rank == 0:
-        n = nx * ny * nz
-        nnz_off = int(nnz.item())
-        alg_spmv = 12 * nnz_off + 24 * n
-        achieved = alg_spmv / (spmv_ms * 1e-3) / 1e9
-        ms_step = dt / args.steps * 1e3
+        os.unlink(path)
+
+    m = measure(rank, world, shape, seed, args.steps, args.warmup)
+    if m is None:
+        raise SystemExit("bench_dist: the workload could not be set up on every rank")
+    extra = None
+    if args.workload == "p7_256" and not args.no_config4:
+        extra = measure(rank, world, (512, 512, 512, 27), seed, min(args.steps, 20), min(args.warmup, 3))
+    if rank == 0:
         out = {
             "metric": "CG iterations/sec (SpMV achieved HBM GB/s in roofline)",
-            "value": args.steps / dt, "unit": "iterations/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True, "scaling": "strong",
+            "value": args.steps / m["dt"], "unit": "iterations/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": m["ms_step"], "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%s: 3-D %d-point Poisson %dx%dx%d, %d rows, slot-major ELL, unpreconditioned CG, "
                                    "z-slab row blocks over %d GPUs, p-halo by ncclSend/Recv overlapped with interior SpMV, "
-                                   "2 ncclAllReduce per iteration" % (args.workload, points, nx, ny, nz, n, world),
-                       "rows": n, "nnz_offdiag": nnz_off, "parallelism": "row-block x%d" % world,
-                       "iter_GBs_algorithmic": (12 * nnz_off + 96 * n) / (ms_step * 1e-3) / 1e9,
-                       "residual_l1_half_first_last": [float(hist[0, 0]), float(hist[-1, 0])]},
+                                   "2 ncclAllReduce per iteration" % (args.workload, points, nx, ny, nz, m["n"], world),
+                       "rows": m["n"], "nnz_offdiag": m["nnz_off"], "parallelism": "row-block x%d" % world,
+                       "iter_GBs_algorithmic": (12 * m["nnz_off"] + 96 * m["n"]) / (m["ms_step"] * 1e-3) / 1e9,
+                       "residual_l1_half_first_last": m["res"]},
             "roofline": {"bound": "hbm", "kernel": "spmv_ell_r2 (interior + boundary launches, incl. exposed halo wait; slowest rank)",
-                         "achieved": achieved, "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
-                         "frac": achieved / (HBM_PEAK_GBS * world), "bytes_per_launch": int(alg_spmv),
-                         "ms_per_launch": spmv_ms, "traffic": None},
+                         "achieved": m["achieved"], "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
+                         "frac": m["achieved"] / (HBM_PEAK_GBS * world), "bytes_per_launch": int(m["alg_spmv"]),
+                         "ms_per_launch": m["spmv_ms"], "traffic": None},
         }
+        if extra is not None:
+            out["config4"] = {"workload": "p27_512: 3-D 27-point Poisson 512^3, %d rows, %d off-diagonals, z-slabs over %d GPUs"
+                                          % (extra["n"], extra["nnz_off"], world),
+                              "value": extra["steps"] / extra["dt"], "unit": "iterations/s", "steps": extra["steps"],
+                              "ms_per_step": extra["ms_step"], "spmv_ms": extra["spmv_ms"],
+                              "spmv_GBs_algorithmic": extra["achieved"],
+                              "spmv_frac_of_peak": extra["achieved"] / (HBM_PEAK_GBS * world),
+                              "one_gpu_reference": "profiles/r01_bench_p27_512_n1.json (105 it/s on one MI355X)"}
         print(json.dumps(out), flush=True)
-    dist.barrier()
+    barrier()
     cga.lib().cgh_comm_destroy()
-    dist.destroy_process_group()

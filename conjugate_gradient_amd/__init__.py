@@ -6,5 +6,5 @@ it carries no compute of its own and raises if the library or a GPU is missing.
 """
 from .binding import (CgOpts, CgReport, DeviceVector, Matrix, lib, init, have_gpu,  # noqa: F401
                       LAYOUT_ELL, LAYOUT_CSR, LAYOUT_SELL, LIB_PATH, cg_solve, Solver, check,
-                      Partition, DistRank, group_start, group_iterate, comm_unique_id, comm_init)
+                      Partition, DistRank, group_start, group_iterate, comm_unique_id, comm_init, comm_allreduce)
 from . import binding  # noqa: F401

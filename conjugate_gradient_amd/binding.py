@@ -106,6 +106,7 @@ def lib():
     L.cgh_comm_unique_id.argtypes = [C.c_char_p]
     L.cgh_comm_init.argtypes = [C.c_int, C.c_int, C.c_char_p]
     L.cgh_comm_destroy.restype = None
+    L.cgh_comm_allreduce_f64.argtypes = [dp, C.c_int, C.c_int]
     L.cgh_dist_from_partition.argtypes = [vp]
     L.cgh_dist_from_partition.restype = vp
     L.cgh_dist_poisson.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_int, C.c_int, vp]
@@ -434,6 +435,13 @@ def comm_unique_id():
     buf = C.create_string_buffer(256)
     check(lib().cgh_comm_unique_id(buf), "cgh_comm_unique_id")
     return buf.raw
+
+
+def comm_allreduce(values, op="sum"):
+    """all-reduce a short list of host doubles over the ranks (RCCL); also a barrier"""
+    a = np.ascontiguousarray(values, dtype=np.float64).copy()
+    check(lib().cgh_comm_allreduce_f64(_D(a), a.size, {"sum": 0, "max": 1, "min": 2}[op]), "cgh_comm_allreduce_f64")
+    return a
 
 
 def comm_init(nranks, rank, id_bytes):

@@ -335,6 +335,33 @@ int cgh_comm_init(int nranks, int rank, const char id_bytes[256])
     return CGH_OK;
 }
 
+// Host-side helper for launchers: all-reduce `count` (<= 64) host doubles over the ranks (op 0 sum, 1 max, 2 min) with the
+// communicator of cgh_comm_init; with one value it doubles as a barrier.  Synchronises the compute stream.
+int cgh_comm_allreduce_f64(double *h_vals, int count, int op)
+{
+    CGH_REQUIRE_READY(CGH_ENODEV);
+    if (!g_rccl.comm) {
+        cgh_set_error("cgh_comm_allreduce_f64: no communicator (cgh_comm_init first)");
+        return CGH_ECOMM;
+    }
+    if (!h_vals || count < 1 || count > 64 || op < 0 || op > 2) return CGH_EINVAL;
+    double *buf = (double *)cgh_alloc(sizeof(double) * 128);
+    if (!buf) return CGH_ENOMEM;
+    hipStream_t s = g_cgh.stream;
+    int         rc = cgh_h2d(buf, h_vals, sizeof(double) * (size_t)count);
+    if (rc == CGH_OK) {
+        const ncclRedOp_t ops[3] = {ncclSum, ncclMax, ncclMin};
+        const ncclResult_t r = g_rccl.AllReduce(buf, buf + 64, (size_t)count, ncclDouble, ops[op], g_rccl.comm, s);
+        if (r != ncclSuccess) {
+            cgh_set_error("cgh_comm_allreduce_f64: %s", g_rccl.GetErrorString(r));
+            rc = CGH_ECOMM;
+        }
+    }
+    if (rc == CGH_OK) rc = cgh_d2h(h_vals, buf + 64, sizeof(double) * (size_t)count);
+    cgh_free(buf);
+    return rc;
+}
+
 void cgh_comm_destroy(void)
 {
     if (g_rccl.comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(g_rccl.comm);

@@ -181,12 +181,14 @@ int     cgh_partition_copy_local(const cgh_partition *p, double *diag, double *e
                                  int64_t *halo_global);
 
 /* RCCL bootstrap: rank 0 calls cgh_comm_unique_id, the 256 bytes (two ncclUniqueIds: one communicator for the
- * halo exchange, one for the all-reduces) travel to the other ranks by any means (bench.py:
- * torch.distributed/gloo broadcast), then every rank calls cgh_comm_init. */
+ * halo exchange, one for the all-reduces) travel to the other ranks by any means (bench_dist.py: a file in /tmp of
+ * the one node), then every rank calls cgh_comm_init. */
 int cgh_comm_preload(void);   /* dlopen RCCL now (call before another copy of librccl gets loaded, e.g. before importing torch) */
 int cgh_comm_unique_id(char out_256_bytes[256]);
 int cgh_comm_init(int nranks, int rank, const char id_256_bytes[256]);
 void cgh_comm_destroy(void);
+/* launcher helper: all-reduce up to 64 host doubles over the ranks (op 0 sum, 1 max, 2 min); one value = a barrier */
+int cgh_comm_allreduce_f64(double *h_vals, int count, int op);
 
 /* Device side of a rank: from a host partition, or generated on the device for the z-slab partition of the
  * seeded Poisson stencils (rank g owns planes [nz*g/G, nz*(g+1)/G)); d_b (may be NULL) gets the local rhs. */
