@@ -458,19 +458,27 @@ int cgh_launch_spmv_ell_range2(const cgh_matrix *m, const double *x, double *y, 
             if (cap == hipStreamCaptureStatusNone) ell_dict_try_build(m, s);
         }
         if (m->dict_state == 1) {
+            // CGH_ELL_VARIANT=3: cached (not non-temporal) y store, for experiments
+            static const int dvar = getenv("CGH_ELL_VARIANT") && atoi(getenv("CGH_ELL_VARIANT")) == 3 ? 3 : VAR_DEFAULT;
+#define CGH_ELL_DICT_LAUNCH(V, MODE)                                                                                       \
+    if (dot_partials)                                                                                                      \
+        launch_r2<true, V, MODE>(m->K, grid, s, m->n, m->diag, m->vals, m->cols8, m->off_tab, x, y, dot_partials, done, rb, re, \
+                                 rb2, re2);                                                                                \
+    else                                                                                                                   \
+        launch_r2<false, V, MODE>(m->K, grid, s, m->n, m->diag, m->vals, m->cols8, m->off_tab, x, y, nullptr, done, rb, re, rb2, \
+                                  re2);
             if (m->dict_mode == 2) {
-                if (dot_partials)
-                    launch_r2<true, VAR_DEFAULT, 2>(m->K, grid, s, m->n, m->diag, m->vals, m->cols8, m->off_tab, x, y, dot_partials,
-                                                    done, rb, re, rb2, re2);
-                else
-                    launch_r2<false, VAR_DEFAULT, 2>(m->K, grid, s, m->n, m->diag, m->vals, m->cols8, m->off_tab, x, y, nullptr, done,
-                                                     rb, re, rb2, re2);
-            } else if (dot_partials)
-                launch_r2<true, VAR_DEFAULT, 1>(m->K, grid, s, m->n, m->diag, m->vals, m->cols8, m->off_tab, x, y, dot_partials,
-                                                done, rb, re, rb2, re2);
-            else
-                launch_r2<false, VAR_DEFAULT, 1>(m->K, grid, s, m->n, m->diag, m->vals, m->cols8, m->off_tab, x, y, nullptr, done,
-                                                 rb, re, rb2, re2);
+                if (dvar == 3) {
+                    CGH_ELL_DICT_LAUNCH(3, 2)
+                } else {
+                    CGH_ELL_DICT_LAUNCH(VAR_DEFAULT, 2)
+                }
+            } else if (dvar == 3) {
+                CGH_ELL_DICT_LAUNCH(3, 1)
+            } else {
+                CGH_ELL_DICT_LAUNCH(VAR_DEFAULT, 1)
+            }
+#undef CGH_ELL_DICT_LAUNCH
             CGH_HIP(hipGetLastError());
             return CGH_OK;
         }

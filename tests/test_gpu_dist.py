@@ -114,4 +114,9 @@ def test_rccl_loop_single_rank(cga):
     assert done > 0 and D.spmv_ms() > 0
     hist = D.history(0, done + 1)
     _check_against_golden(done + 1, hist, x.to_host(), g)
+    # the launcher helper bench_dist.py uses for its barriers / max-over-ranks
+    assert cga.comm_allreduce([1.5, -2.0, 7.0], "sum").tolist() == [1.5, -2.0, 7.0]
+    assert cga.comm_allreduce([3.25], "max").tolist() == [3.25] and cga.comm_allreduce([3.25], "min").tolist() == [3.25]
     cga.lib().cgh_comm_destroy()
+    with pytest.raises(RuntimeError):
+        cga.comm_allreduce([1.0])
