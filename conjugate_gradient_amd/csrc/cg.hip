@@ -108,9 +108,10 @@ struct cgh_solver {
 };
 
 // The strict-mode sums of the solver (modes: see seq_sums): parallel order-exact sums for long vectors, one lane otherwise.
-static int strict_sums(cgh_solver *sv, const double *a, const double *b, const double *c, int mode, int iter, hipStream_t s)
+static int strict_sums(cgh_solver *sv, const double *a, const double *b, const double *c, int mode, int iter, hipStream_t s,
+                       bool presummed = false)
 {
-    if (sv->xs) return cgh_xsum_launch(sv->xs, sv->n, a, b, c, mode, sv->hist, iter, sv->tol, sv->done, nullptr, s);
+    if (sv->xs) return cgh_xsum_launch(sv->xs, sv->n, a, b, c, mode, sv->hist, iter, sv->tol, sv->done, nullptr, s, presummed);
     hipLaunchKernelGGL(seq_sums, dim3(1), dim3(CGH_BLOCK), 0, s, sv->n, a, b, c, mode, sv->hist, iter, sv->tol, sv->done,
                        (double *)nullptr);
     return CGH_OK;
@@ -286,7 +287,13 @@ static int enqueue_iterations(cgh_solver *sv, int count, int time_kernels, bool 
             sv->kev.push_back(b);
             CGH_HIP(hipEventRecord(a, s));
         }
+        // strict mode with the parallel sums: the SpMV leaves p.Ap per 128-row cell (their binade prediction) if it can
+        g_cgh.cell_sums = sv->strict && sv->precond == CGH_PRECOND_NONE ? cgh_xsum_cellsums(sv->xs) : nullptr;
+        g_cgh.cell_sums_written = false;
         int rc = cgh_launch_spmv(sv->m, dp, dAp, sv->strict ? nullptr : dA, &gridA, dd, s);
+        const bool pAp_presummed = g_cgh.cell_sums_written;
+        g_cgh.cell_sums = nullptr;
+        g_cgh.cell_sums_written = false;
         if (rc) return rc;
         g_cgh.sweep_reverse = 0;
         if (time_kernels) CGH_HIP(hipEventRecord(sv->kev.back(), s));
@@ -297,11 +304,13 @@ static int enqueue_iterations(cgh_solver *sv, int count, int time_kernels, bool 
             hipLaunchKernelGGL(pcg_update_xp, dim3(vg), dim3(CGH_BLOCK), 0, s, n, d_x, (const double *)dr, dp, dg,
                                (const double *)dB, vg, dh, iter, tol, dd);
         } else if (sv->strict) {
-            rc = strict_sums(sv, dp, dAp, nullptr, 1, iter, s);
+            rc = strict_sums(sv, dp, dAp, nullptr, 1, iter, s, pAp_presummed);
             if (rc) return rc;
+            // with the parallel sums, the r update also leaves their per-cell approximate sums (one sweep over r less)
             hipLaunchKernelGGL((cg_update_r<1, 3>), dim3(vg), dim3(CGH_BLOCK), 0, s, n, dr, (const double *)dAp,
-                               (const double *)dA, gridA, dB, dh, iter, (const int *)dd, rev2, (const double *)nullptr);
-            rc = strict_sums(sv, dr, dr, dr, 2, iter, s);
+                               (const double *)dA, gridA, dB, dh, iter, (const int *)dd, rev2, (const double *)nullptr,
+                               cgh_xsum_cellsums(sv->xs), cgh_xsum_cells(sv->xs));
+            rc = strict_sums(sv, dr, dr, dr, 2, iter, s, sv->xs != nullptr);
             if (rc) return rc;
             hipLaunchKernelGGL((cg_update_xp<1, 3>), dim3(vg), dim3(CGH_BLOCK), 0, s, n, d_x, (const double *)dr, dp,
                                (const double *)dB, vg, dh, iter, tol, dd, rev1, (const double *)nullptr);

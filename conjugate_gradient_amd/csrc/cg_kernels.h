@@ -84,7 +84,8 @@ template <int MODE, int VV>
 __global__ __launch_bounds__(CGH_BLOCK) void cg_update_r(int64_t n, double *__restrict__ r, const double *__restrict__ Ap,
                                                         const double *__restrict__ pAp_partials, int pAp_count,
                                                         double *__restrict__ out_partials, double *hist, int iter,
-                                                        const int *__restrict__ done, int rev, const double *__restrict__ gs)
+                                                        const int *__restrict__ done, int rev, const double *__restrict__ gs,
+                                                        double *__restrict__ cellsum = nullptr, int64_t ncells = 0)
 {
     constexpr bool STRICT = MODE == 1;
     __shared__ double lds[4];
@@ -114,15 +115,27 @@ __global__ __launch_bounds__(CGH_BLOCK) void cg_update_r(int64_t n, double *__re
     const int64_t chunks = (pairs + CGH_BLOCK - 1) / CGH_BLOCK;
     for (int64_t cc = blockIdx.x; cc < chunks; cc += gridDim.x) {
         const int64_t k = (rev ? chunks - 1 - cc : cc) * CGH_BLOCK + threadIdx.x;
-        if (k >= pairs) continue;
-        const double2 rv = ld2<VV>(r, k);
-        const double2 av = ld2<VV>(Ap, k);
-        // reference vec_axpy: out = a + alpha*b (vec.c:88-94), called with -alpha (cg.c:469)
-        const double2 rn = make_double2(madd_rn(rv.x, nalpha, av.x), madd_rn(rv.y, nalpha, av.y));
-        st2<(VV & 4) != 0>(r, k, rn.x, rn.y);
+        double2       rn = make_double2(0.0, 0.0);
+        if (k < pairs) {
+            const double2 rv = ld2<VV>(r, k);
+            const double2 av = ld2<VV>(Ap, k);
+            // reference vec_axpy: out = a + alpha*b (vec.c:88-94), called with -alpha (cg.c:469)
+            rn = make_double2(madd_rn(rv.x, nalpha, av.x), madd_rn(rv.y, nalpha, av.y));
+            st2<(VV & 4) != 0>(r, k, rn.x, rn.y);
+        }
         if constexpr (!STRICT) {
             rr += rn.x * rn.x + rn.y * rn.y;
             l1 += fabs(rn.x) + fabs(rn.y);
+        } else if (cellsum != nullptr) {
+            // A wave's 64 pairs are the 128 elements of one cell of the order-exact sums (xsum.hip): leave the cell's
+            // approximate r.r and |r|_1 for their binade prediction, which saves them a sweep over r.  (An odd n's last
+            // element is missing from the last cell's sum: the prediction is only a guess, the sums stay exact.)
+            const double  q = wave_sum(rn.x * rn.x + rn.y * rn.y), a = wave_sum(fabs(rn.x) + fabs(rn.y));
+            const int64_t cell = k >> 6;
+            if ((threadIdx.x & 63) == 0 && cell < ncells) {
+                cellsum[cell] = q;
+                cellsum[ncells + cell] = a;
+            }
         }
     }
     if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {

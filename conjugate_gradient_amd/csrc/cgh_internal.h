@@ -17,6 +17,10 @@ struct cgh_context {
     hipStream_t stream = nullptr;       // compute stream: every kernel of the solver
     hipStream_t comm_stream = nullptr;  // halo exchange / collectives (multi-GPU)
     int         sweep_reverse = 0;      // 1: the next launches walk their arrays from the end (serpentine sweeps)
+    // strict mode: the next SpMV may leave x.y summed per 128-row cell in cell_sums (xsum.hip's binade prediction);
+    // the launcher sets cell_sums_written if the kernel it chose did so
+    double     *cell_sums = nullptr;
+    bool        cell_sums_written = false;
     char        err[512] = {0};
 };
 extern cgh_context g_cgh;
@@ -112,5 +116,9 @@ void      cgh_xsum_free(cgh_xsum *w);
 // Same contract as the seq_sums kernel (cg_kernels.h): dot = sum a[i]*b[i] (a != NULL), l1 = sum |c[i]| (c != NULL), both
 // added strictly left to right; mode 0: out = {dot, l1}; 1: alpha; 2: res, rr, beta, done; 3: initial res, rr.
 // a, b, c must either be (a, b, NULL), (NULL, NULL, c) or (v, v, v).
+// presummed: the approximate per-cell sums (128 elements each; slot 0 = dot at [0, cells), slot 1 = l1 at [cells, 2 cells))
+// were already written to cgh_xsum_cellsums() by the kernel that produced the vector; else a sweep computes them.
 int cgh_xsum_launch(cgh_xsum *w, int64_t n, const double *a, const double *b, const double *c, int mode, double *hist,
-                    int iter, double tol, int *done, double *out, hipStream_t s);
+                    int iter, double tol, int *done, double *out, hipStream_t s, bool presummed = false);
+double *cgh_xsum_cellsums(cgh_xsum *w);
+int64_t cgh_xsum_cells(const cgh_xsum *w);

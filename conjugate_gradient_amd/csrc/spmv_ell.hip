@@ -59,7 +59,7 @@ __device__ __forceinline__ i2_t load_cols(const void *__restrict__ cols, const i
     }
 }
 
-template <int KT, bool DOT, int VAR, int DICT = 0>
+template <int KT, int DOT, int VAR, int DICT = 0>
 __global__ __launch_bounds__(CGH_BLOCK) void spmv_ell_r2(int64_t n, int Krt, const double *__restrict__ diag,
                                                         const double *__restrict__ vals, const void *__restrict__ cols,
                                                         const int *__restrict__ off_tab,
@@ -178,9 +178,15 @@ __global__ __launch_bounds__(CGH_BLOCK) void spmv_ell_r2(int64_t n, int Krt, con
         } else {
             *reinterpret_cast<double2 *>(y + i0) = make_double2(a0, a1);
         }
-        if constexpr (DOT) local += xi.x * a0 + xi.y * a1;
+        if constexpr (DOT == 1) local += xi.x * a0 + xi.y * a1;
+        if constexpr (DOT == 2) {
+            // strict mode: a wave's 64 row pairs are one 128-row cell of the order-exact sums (xsum.hip); its approximate
+            // x.y goes to partials[cell].  Launched only for one full range with n % 128 == 0: every wave is full or idle.
+            const double q = wave_sum(xi.x * a0 + xi.y * a1);
+            if ((threadIdx.x & 63) == 0) partials[pr >> 6] = q;
+        }
     }
-    if constexpr (DOT) {
+    if constexpr (DOT == 1) {
         const double tot = block_sum_256(local, lds);
         if (threadIdx.x == 0) partials[blockIdx.x] = tot;
     }
@@ -219,7 +225,7 @@ __global__ __launch_bounds__(CGH_BLOCK) void spmv_ell_r1(int64_t n, int K, const
 
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
-template <bool DOT, int VAR, int DICT = 0>
+template <int DOT, int VAR, int DICT = 0>
 void launch_r2(int K, int grid, hipStream_t s, int64_t n, const double *diag, const double *vals, const void *cols,
                const int *off_tab, const double *x, double *y, double *partials, const int *done, int64_t rb, int64_t re,
                int64_t rb2, int64_t re2)
@@ -456,6 +462,21 @@ int cgh_launch_spmv_ell_range2(const cgh_matrix *m, const double *x, double *y, 
             hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
             (void)hipStreamIsCapturing(s, &cap);
             if (cap == hipStreamCaptureStatusNone) ell_dict_try_build(m, s);
+        }
+        // strict mode's per-cell sums of x.y instead of per-workgroup partials
+        if (g_cgh.cell_sums != nullptr && dot_partials == nullptr && rb == 0 && re == m->n && re2 <= rb2 && m->n % 128 == 0) {
+            if (m->dict_state == 1 && m->dict_mode == 2)
+                launch_r2<2, VAR_DEFAULT, 2>(m->K, grid, s, m->n, m->diag, m->vals, m->cols8, m->off_tab, x, y, g_cgh.cell_sums, done,
+                                             rb, re, rb2, re2);
+            else if (m->dict_state == 1)
+                launch_r2<2, VAR_DEFAULT, 1>(m->K, grid, s, m->n, m->diag, m->vals, m->cols8, m->off_tab, x, y, g_cgh.cell_sums, done,
+                                             rb, re, rb2, re2);
+            else
+                launch_r2<2, VAR_DEFAULT, 0>(m->K, grid, s, m->n, m->diag, m->vals, m->cols, nullptr, x, y, g_cgh.cell_sums, done, rb,
+                                             re, rb2, re2);
+            g_cgh.cell_sums_written = true;
+            CGH_HIP(hipGetLastError());
+            return CGH_OK;
         }
         if (m->dict_state == 1) {
             // CGH_ELL_VARIANT=3: cached (not non-temporal) y store, for experiments

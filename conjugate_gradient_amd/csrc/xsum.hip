@@ -94,6 +94,22 @@ __global__ __launch_bounds__(256) void xs_cell_sums(int64_t n, const double *__r
     }
 }
 
+// groupsum[slot][g] = sum of the group's 64 cell sums, when the cell sums came from the kernel that produced the
+// vector (cg_update_r in strict mode writes them as a by-product: one sweep over r less).  One wave per (slot, group).
+__global__ __launch_bounds__(256) void xs_group_sums(int64_t ncells, int64_t ngroups, const double *__restrict__ cellsum,
+                                                    double *__restrict__ groupsum, int slot_lo, int slot_hi)
+{
+    const int     lane = threadIdx.x & 63;
+    const int64_t wv = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t per = ngroups;
+    const int     slot = slot_lo + (int)(wv / per);
+    const int64_t g = wv % per;
+    if (slot > slot_hi) return;
+    const int64_t cell = g * XS_GROUP + lane;
+    const double  v = wave_sum(cell < ncells ? cellsum[slot * ncells + cell] : 0.0);
+    if (lane == 0) groupsum[slot * ngroups + g] = v;
+}
+
 // gprefix[slot][g] = groupsum[slot][0] + ... + groupsum[slot][g-1] (approximate: any order)
 __global__ __launch_bounds__(256) void xs_group_scan(int64_t ngroups, const double *__restrict__ groupsum, double *__restrict__ gprefix)
 {
@@ -464,11 +480,19 @@ __global__ __launch_bounds__(128) void xs_drive(int64_t n, const double *__restr
 }
 
 template <int KIND>
-int launch_all(cgh_xsum *w, int64_t n, const double *a, const double *b, const double *c, int mode, double *hist, int iter,
+int launch_all(cgh_xsum *w, bool presummed, int64_t n, const double *a, const double *b, const double *c, int mode, double *hist, int iter,
                double tol, int *done, double *out, hipStream_t s)
 {
     const unsigned ng = (unsigned)w->ngroups;
-    hipLaunchKernelGGL((xs_cell_sums<KIND>), dim3(ng), dim3(256), 0, s, n, a, b, c, w->ncells, w->ngroups, w->cellsum, w->groupsum);
+    if (presummed) {
+        constexpr int S0 = KIND == XS_L1 ? 1 : 0, S1 = KIND == XS_DOT ? 0 : 1;
+        const int64_t waves = (int64_t)(S1 - S0 + 1) * w->ngroups;
+        hipLaunchKernelGGL(xs_group_sums, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, w->ncells, w->ngroups,
+                           (const double *)w->cellsum, w->groupsum, S0, S1);
+    } else {
+        hipLaunchKernelGGL((xs_cell_sums<KIND>), dim3(ng), dim3(256), 0, s, n, a, b, c, w->ncells, w->ngroups, w->cellsum,
+                           w->groupsum);
+    }
     // few groups: every workgroup of xs_summarize adds the group sums before it itself (one launch less)
     const double *prefix = nullptr;
     if (w->ngroups > 4096) {
@@ -515,8 +539,11 @@ void cgh_xsum_free(cgh_xsum *w)
     delete w;
 }
 
+double *cgh_xsum_cellsums(cgh_xsum *w) { return w ? w->cellsum : nullptr; }
+int64_t cgh_xsum_cells(const cgh_xsum *w) { return w ? w->ncells : 0; }
+
 int cgh_xsum_launch(cgh_xsum *w, int64_t n, const double *a, const double *b, const double *c, int mode, double *hist,
-                    int iter, double tol, int *done, double *out, hipStream_t s)
+                    int iter, double tol, int *done, double *out, hipStream_t s, bool presummed)
 {
     if (!w || n != w->n) {
         cgh_set_error("cgh_xsum_launch: workspace was created for another length");
@@ -528,9 +555,9 @@ int cgh_xsum_launch(cgh_xsum *w, int64_t n, const double *a, const double *b, co
         cgh_set_error("cgh_xsum_launch: vectors must be 16-byte aligned");
         return CGH_EINVAL;
     }
-    if (a && b && !c) return launch_all<XS_DOT>(w, n, a, b, c, mode, hist, iter, tol, done, out, s);
-    if (!a && !b && c) return launch_all<XS_L1>(w, n, a, b, c, mode, hist, iter, tol, done, out, s);
-    if (a && a == b && a == c) return launch_all<XS_BOTH_SAME>(w, n, a, b, c, mode, hist, iter, tol, done, out, s);
+    if (a && b && !c) return launch_all<XS_DOT>(w, presummed, n, a, b, c, mode, hist, iter, tol, done, out, s);
+    if (!a && !b && c) return launch_all<XS_L1>(w, presummed, n, a, b, c, mode, hist, iter, tol, done, out, s);
+    if (a && a == b && a == c) return launch_all<XS_BOTH_SAME>(w, presummed, n, a, b, c, mode, hist, iter, tol, done, out, s);
     cgh_set_error("cgh_xsum_launch: unsupported operand combination");
     return CGH_EINVAL;
 }
