@@ -190,7 +190,9 @@ __global__ __launch_bounds__(256) void xs_summarize(int64_t n, const double *__r
     double before[2] = {0.0, 0.0};
 #pragma unroll
     for (int slot = S0; slot <= S1; ++slot)
-        before[slot] = gprefix ? gprefix[slot * ngroups + g] : block_sum_partials(groupsum + slot * ngroups, (int)g, 1, red);
+        before[slot] = gprefix    ? gprefix[slot * ngroups + g]
+                       : groupsum ? block_sum_partials(groupsum + slot * ngroups, (int)g, 1, red)
+                                  : block_sum_partials(cellsum + slot * ncells, (int)(g * XS_GROUP), 1, red);  // few cells
     if (wave >= S0 && wave <= S1) {
         const int64_t cell = g * XS_GROUP + lane;
         const double  v = cell < ncells ? cellsum[wave * ncells + cell] : 0.0;
@@ -484,7 +486,10 @@ int launch_all(cgh_xsum *w, bool presummed, int64_t n, const double *a, const do
                double tol, int *done, double *out, hipStream_t s)
 {
     const unsigned ng = (unsigned)w->ngroups;
-    if (presummed) {
+    const double *gsum = w->groupsum;
+    if (presummed && w->ncells <= 4096) {
+        gsum = nullptr;  // every workgroup of xs_summarize adds up the cell sums before its group itself: no launch here
+    } else if (presummed) {
         constexpr int S0 = KIND == XS_L1 ? 1 : 0, S1 = KIND == XS_DOT ? 0 : 1;
         const int64_t waves = (int64_t)(S1 - S0 + 1) * w->ngroups;
         hipLaunchKernelGGL(xs_group_sums, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, w->ncells, w->ngroups,
@@ -500,7 +505,7 @@ int launch_all(cgh_xsum *w, bool presummed, int64_t n, const double *a, const do
         prefix = w->gprefix;
     }
     hipLaunchKernelGGL((xs_summarize<KIND>), dim3(ng), dim3(256), 0, s, n, a, b, c, w->ncells, w->ngroups,
-                       (const double *)w->cellsum, (const double *)w->groupsum, prefix, w->cells, w->groups);
+                       (const double *)w->cellsum, gsum, prefix, w->cells, w->groups);
     hipLaunchKernelGGL((xs_drive<KIND>), dim3(1), dim3(128), 0, s, n, a, b, c, w->ncells, w->ngroups,
                        (const xs_summary *)w->cells, (const xs_summary *)w->groups, mode, hist, iter, tol, done, out);
     CGH_HIP(hipGetLastError());
