@@ -185,7 +185,10 @@ __global__ __launch_bounds__(256) void xs_summarize(int64_t n, const double *__r
     __shared__ xs_summary sm[2][XS_GROUP];
     __shared__ double     red[4];
     const int     lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t g = blockIdx.x;
+    // groups == NULL ("flat", few cells): four workgroups per group, one pass of 16 cells each, no group summary --
+    // the whole problem is then a handful of workgroups, and their serial depth is what counts
+    const bool    flat = groups == nullptr;
+    const int64_t g = flat ? blockIdx.x >> 2 : blockIdx.x;
     // approximate sum of everything before this group: from the scan kernel, or (few groups) summed here
     double before[2] = {0.0, 0.0};
 #pragma unroll
@@ -206,8 +209,9 @@ __global__ __launch_bounds__(256) void xs_summarize(int64_t n, const double *__r
     }
     __syncthreads();
     const int sub = threadIdx.x & 15;  // position inside the cell's 16 lanes
+    const int pass_lo = flat ? (int)(blockIdx.x & 3) : 0, pass_hi = flat ? pass_lo + 1 : 4;
 #pragma unroll 1
-    for (int pass = 0; pass < 4; ++pass) {
+    for (int pass = pass_lo; pass < pass_hi; ++pass) {
         const int     ci = pass * 16 + (threadIdx.x >> 4);
         const int64_t cell = g * XS_GROUP + ci;
         double        t[2][8];
@@ -250,6 +254,7 @@ __global__ __launch_bounds__(256) void xs_summarize(int64_t n, const double *__r
             }
         }
     }
+    if (flat) return;
     __syncthreads();
     if (wave >= S0 && wave <= S1) {
         const xs_summary q = wave_join(sm[wave][lane]);
@@ -349,28 +354,38 @@ __device__ __forceinline__ void xs_cell_terms(int slot, int64_t n, const double 
     t1 = slot ? t[1][1] : t[0][1];
 }
 
-constexpr int XS_PF_CELLS = 6;  // cells of a group whose elements are fetched ahead (those flagged irregular)
+constexpr int XS_PF_CELLS = 8;  // cells of a batch whose elements are fetched ahead (those flagged irregular)
 
-// The cells [c0, c0+ccnt) of one group (summary of cell c0+lane in C), applied to s.  The serial chain here is
-// memory latency, so the elements of the cells that are KNOWN to need the element-by-element path (irregular flag:
-// tie, binade change, ...) are requested up front, all at once; a cell that fails only the range check against the
-// actual running sum is fetched when it is met.
+// Elements of the cells of a batch that are KNOWN to need the element-by-element path (irregular flag: tie, binade
+// change, ...), requested all at once: the serial chain of the driver is memory latency.
+struct xs_prefetch {
+    int    idx[XS_PF_CELLS];
+    double t0[XS_PF_CELLS], t1[XS_PF_CELLS];
+};
+
 template <int KIND>
-__device__ __forceinline__ double xs_walk_cells(double s, int slot, int64_t n, const double *__restrict__ a,
-                                                const double *__restrict__ b, const double *__restrict__ c, int64_t c0,
-                                                int ccnt, const xs_summary &C, double *stage)
+__device__ __forceinline__ void xs_prefetch_cells(xs_prefetch &f, int slot, int64_t n, const double *__restrict__ a,
+                                                  const double *__restrict__ b, const double *__restrict__ c, int64_t c0,
+                                                  int ccnt, const xs_summary &C)
 {
     const int          lane = threadIdx.x & 63;
     unsigned long long flagged = __ballot(lane < ccnt && (C.meta & XS_IRREGULAR));
-    int                pf_idx[XS_PF_CELLS];
-    double             pf_t0[XS_PF_CELLS], pf_t1[XS_PF_CELLS];
 #pragma unroll
     for (int j = 0; j < XS_PF_CELLS; ++j) {
-        pf_idx[j] = flagged ? (int)__builtin_ctzll(flagged) : -1;
+        f.idx[j] = flagged ? (int)__builtin_ctzll(flagged) : -1;
         flagged &= flagged - 1;
-        pf_t0[j] = pf_t1[j] = 0.0;
-        if (pf_idx[j] >= 0) xs_cell_terms<KIND>(slot, n, a, b, c, c0 + pf_idx[j], pf_t0[j], pf_t1[j]);
+        f.t0[j] = f.t1[j] = 0.0;
+        if (f.idx[j] >= 0) xs_cell_terms<KIND>(slot, n, a, b, c, c0 + f.idx[j], f.t0[j], f.t1[j]);
     }
+}
+
+// The cells [c0, c0+ccnt) of one batch (summary of cell c0+lane in C), applied to s.  A cell that fails only the range
+// check against the actual running sum (not prefetched) is fetched when it is met.
+template <int KIND>
+__device__ __forceinline__ double xs_walk_cells(double s, int slot, int64_t n, const double *__restrict__ a,
+                                                const double *__restrict__ b, const double *__restrict__ c, int64_t c0,
+                                                int ccnt, const xs_summary &C, double *stage, const xs_prefetch &f)
+{
     int cstart = 0;
     while (cstart < ccnt) {
         const int cf = xs_batch(C, cstart, ccnt, s);
@@ -379,14 +394,43 @@ __device__ __forceinline__ double xs_walk_cells(double s, int slot, int64_t n, c
         bool   have = false;
 #pragma unroll
         for (int j = 0; j < XS_PF_CELLS; ++j)
-            if (pf_idx[j] == cf) {
-                t0 = pf_t0[j];
-                t1 = pf_t1[j];
+            if (f.idx[j] == cf) {
+                t0 = f.t0[j];
+                t1 = f.t1[j];
                 have = true;
             }
         if (!have) xs_cell_terms<KIND>(slot, n, a, b, c, c0 + cf, t0, t1);
         s = xs_chain(s, t0, t1, stage);
         cstart = cf + 1;
+    }
+    return s;
+}
+
+// Few cells (<= 4096): no group level.  The cell summaries are walked 64 at a time, two batches ahead in flight: when
+// batch k is walked, its summaries and the elements of its flagged cells arrived while batch k-1 was walked.
+template <int KIND>
+__device__ double xs_walk_flat(int slot, int64_t n, const double *__restrict__ a, const double *__restrict__ b,
+                               const double *__restrict__ c, int64_t ncells, const xs_summary *__restrict__ cells, double *stage)
+{
+    const int lane = threadIdx.x & 63;
+    cells += slot * ncells;
+    auto load = [&](int64_t c0) {
+        xs_summary q = xs_identity();
+        if (c0 + lane < ncells) q = cells[c0 + lane];
+        return q;
+    };
+    auto count = [&](int64_t c0) { return (int)(ncells - c0 < 64 ? (ncells - c0 > 0 ? ncells - c0 : 0) : 64); };
+    double      s = 0.0;
+    xs_summary  C0 = load(0), C1 = load(64);
+    xs_prefetch f0, f1;
+    xs_prefetch_cells<KIND>(f0, slot, n, a, b, c, 0, count(0), C0);
+    for (int64_t c0 = 0; c0 < ncells; c0 += 64) {
+        const xs_summary C2 = load(c0 + 128);
+        xs_prefetch_cells<KIND>(f1, slot, n, a, b, c, c0 + 64, count(c0 + 64), C1);
+        s = xs_walk_cells<KIND>(s, slot, n, a, b, c, c0, count(c0), C0, stage, f0);
+        C0 = C1;
+        C1 = C2;
+        f0 = f1;
     }
     return s;
 }
@@ -432,7 +476,9 @@ __device__ double xs_walk(int slot, int64_t n, const double *__restrict__ a, con
             } else if (lane < ccnt) {
                 C = cells[c0 + lane];
             }
-            s = xs_walk_cells<KIND>(s, slot, n, a, b, c, c0, ccnt, C, stage);
+            xs_prefetch pf;
+            xs_prefetch_cells<KIND>(pf, slot, n, a, b, c, c0, ccnt, C);
+            s = xs_walk_cells<KIND>(s, slot, n, a, b, c, c0, ccnt, C, stage, pf);
             start = f + 1;
         }
     }
@@ -453,7 +499,8 @@ __global__ __launch_bounds__(128) void xs_drive(int64_t n, const double *__restr
     __syncthreads();
     const bool frozen = done != nullptr && mode != 3 && mode != 0 && *done != 0;
     if (!frozen && wave >= S0 && wave <= S1) {
-        const double s = xs_walk<KIND>(wave, n, a, b, c, ncells, ngroups, cells, groups, stage[wave]);
+        const double s = groups != nullptr ? xs_walk<KIND>(wave, n, a, b, c, ncells, ngroups, cells, groups, stage[wave])
+                                           : xs_walk_flat<KIND>(wave, n, a, b, c, ncells, cells, stage[wave]);
         if ((threadIdx.x & 63) == 0) res[wave] = s;
     }
     __syncthreads();
@@ -504,10 +551,12 @@ int launch_all(cgh_xsum *w, bool presummed, int64_t n, const double *a, const do
         hipLaunchKernelGGL(xs_group_scan, dim3(1), dim3(256), 0, s, w->ngroups, (const double *)w->groupsum, w->gprefix);
         prefix = w->gprefix;
     }
-    hipLaunchKernelGGL((xs_summarize<KIND>), dim3(ng), dim3(256), 0, s, n, a, b, c, w->ncells, w->ngroups,
-                       (const double *)w->cellsum, gsum, prefix, w->cells, w->groups);
+    const bool  flat = w->ncells <= 4096;  // few cells: no group level (xs_walk_flat)
+    xs_summary *grp = flat ? nullptr : w->groups;
+    hipLaunchKernelGGL((xs_summarize<KIND>), dim3(flat ? 4 * ng : ng), dim3(256), 0, s, n, a, b, c, w->ncells, w->ngroups,
+                       (const double *)w->cellsum, gsum, prefix, w->cells, grp);
     hipLaunchKernelGGL((xs_drive<KIND>), dim3(1), dim3(128), 0, s, n, a, b, c, w->ncells, w->ngroups,
-                       (const xs_summary *)w->cells, (const xs_summary *)w->groups, mode, hist, iter, tol, done, out);
+                       (const xs_summary *)w->cells, (const xs_summary *)grp, mode, hist, iter, tol, done, out);
     CGH_HIP(hipGetLastError());
     return CGH_OK;
 }

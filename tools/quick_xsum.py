@@ -19,7 +19,7 @@ def run(nx, ny, nz, iters, strict, xsum_min):
     return rep.solve_ms / iters * 1e3, hist
 
 
-for (nx, ny, nz, it_seq) in ((40, 40, 20, 50), (400, 320, 1, 50), (128, 128, 64, 20), (256, 256, 64, 5), (256, 256, 256, 2)):
+for (nx, ny, nz, it_seq) in ((16, 16, 8, 50), (16, 16, 16, 50), (20, 20, 20, 50), (40, 40, 20, 50), (400, 320, 1, 50), (128, 128, 64, 20), (256, 256, 64, 5), (256, 256, 256, 2)):
     n = nx * ny * nz
     t_x, h_x = run(nx, ny, nz, 50, 1, 0)
     t_s, h_s = run(nx, ny, nz, it_seq, 1, -1)
