@@ -50,7 +50,7 @@ int vec_grid(int64_t n)
 int64_t xsum_min_rows()
 {
     const char *e = getenv("CGH_XSUM_MIN_ROWS");
-    const int64_t v = e ? atoll(e) : 8192;  // measured crossover on MI355X (~100 us/iteration either way)
+    const int64_t v = e ? atoll(e) : 4096;  // measured crossover on MI355X (~70 us/iteration either way)
     return v < 0 ? INT64_MAX : v;
 }
 

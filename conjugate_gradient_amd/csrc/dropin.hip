@@ -8,7 +8,7 @@
 //
 // Environment: CG_HIP_DEVICE (default 0), CG_HIP_QUIET=1 (suppress the reference's printf chatter),
 // CG_HIP_MODE=strict|fast (reduction order of the CG dots: strict = the reference's left-to-right sums,
-// bit-identical trajectory, the default at every size -- one lane below 8192 rows, the order-exact parallel
+// bit-identical trajectory, the default at every size -- one lane below 4096 rows, the order-exact parallel
 // sums of xsum.hip above; fast = tree reductions, ~2.4x faster per iteration at 16.7M rows).
 #include <cmath>
 #include <vector>
