@@ -80,16 +80,19 @@ __global__ __launch_bounds__(256) void expand_row_ptr(int64_t n, const int *__re
 // Memory order is the order in which the reference's SpMV visits them (slot-major: ell.c:971-998,
 // row-major: ell.c:182-210), and each visit adds into y[row] and then y[col] -- the same two placements
 // per entry, in the same order, as the COO conversion.  flags/pos: 1 per non-pad entry and its exclusive scan.
-__global__ __launch_bounds__(256) void ell_flags(int64_t total, const int *__restrict__ ec, int *__restrict__ flag)
+// (entries at memory position >= limit count as padding: the reference stops there on a malformed entry)
+__global__ __launch_bounds__(256) void ell_flags(int64_t total, int64_t limit, const int *__restrict__ ec, int *__restrict__ flag)
 {
-    for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < total; k += (int64_t)gridDim.x * 256) flag[k] = ec[k] != -1;
+    for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < total; k += (int64_t)gridDim.x * 256)
+        flag[k] = ec[k] != -1 && k < limit;
 }
-__global__ __launch_bounds__(256) void ell_compact(int64_t total, int64_t n, int K, int row_major, const double *__restrict__ ev,
-                                                  const int *__restrict__ ec, const int64_t *__restrict__ pos,
-                                                  double *__restrict__ v, int *__restrict__ rows, int *__restrict__ cols)
+__global__ __launch_bounds__(256) void ell_compact(int64_t total, int64_t limit, int64_t n, int K, int row_major,
+                                                  const double *__restrict__ ev, const int *__restrict__ ec,
+                                                  const int64_t *__restrict__ pos, double *__restrict__ v, int *__restrict__ rows,
+                                                  int *__restrict__ cols)
 {
     for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < total; k += (int64_t)gridDim.x * 256) {
-        if (ec[k] == -1) continue;
+        if (ec[k] == -1 || k >= limit) continue;
         const int64_t at = pos[k];
         v[at] = ev[k];
         cols[at] = ec[k];
@@ -189,7 +192,10 @@ int run_cg(const char *banner, const cgh_matrix *m, const double *b, double *x, 
     return rep.ret;
 }
 
-cgh_matrix *matrix_from_upper_ell(int n, int K, const double *diag, const double *ev, const int *ec, bool row_major, int layout)
+// stop: memory position (in the caller's ELL arrays) of the first malformed entry, -1 if none: everything from there on is
+// left out, which is exactly what the reference's loops have accumulated when they return early.
+cgh_matrix *matrix_from_upper_ell(int n, int K, const double *diag, const double *ev, const int *ec, bool row_major, int layout,
+                                  int64_t stop = -1)
 {
     // upper ELL -> COO in visiting order -> full layout (see ell_compact).  The row-major SpMV of the reference
     // (ell.c:182-210) adds diag[i]*x[i] when it reaches row i, i.e. AFTER the contributions scattered into y[i]
@@ -197,6 +203,8 @@ cgh_matrix *matrix_from_upper_ell(int n, int K, const double *diag, const double
     hipStream_t  s = g_cgh.stream;
     const int    KK = row_major ? K + 1 : K;
     const int64_t total = (int64_t)n * KK;
+    // position of the stop entry in the (possibly diagonal-extended) list that is compacted below
+    const int64_t limit = stop < 0 ? total : (row_major ? (stop / K) * KK + stop % K + 1 : stop);
     dbuf<double> dd(diag, (size_t)n), dv0(ev, (size_t)n * K), dv((size_t)(row_major ? total : 0));
     dbuf<int>    dc0(ec, (size_t)n * K), dc((size_t)(row_major ? total : 0)), flag((size_t)total + 1);
     dbuf<int64_t> pos((size_t)total + 2);
@@ -210,7 +218,7 @@ cgh_matrix *matrix_from_upper_ell(int n, int K, const double *diag, const double
         src_c = dc.p;
     }
     if (hipMemsetAsync(flag.p + total, 0, sizeof(int), s) != hipSuccess) return nullptr;
-    if (total > 0) hipLaunchKernelGGL(ell_flags, dim3(grid_for(total)), dim3(256), 0, s, total, src_c, flag.p);
+    if (total > 0) hipLaunchKernelGGL(ell_flags, dim3(grid_for(total)), dim3(256), 0, s, total, limit, src_c, flag.p);
     if (cgh_exclusive_scan_i32_to_i64_fwd(flag.p, pos.p, total + 1, s) != CGH_OK) return nullptr;
     int64_t U = 0;
     if (cgh_d2h(&U, pos.p + total, sizeof(int64_t)) != CGH_OK) return nullptr;
@@ -218,8 +226,8 @@ cgh_matrix *matrix_from_upper_ell(int n, int K, const double *diag, const double
     dbuf<int>    cr((size_t)U), cc((size_t)U);
     if (!cv.ok() || !cr.ok() || !cc.ok()) return nullptr;
     if (total > 0)
-        hipLaunchKernelGGL(ell_compact, dim3(grid_for(total)), dim3(256), 0, s, total, (int64_t)n, KK, row_major ? 1 : 0, src_v,
-                           src_c, (const int64_t *)pos.p, cv.p, cr.p, cc.p);
+        hipLaunchKernelGGL(ell_compact, dim3(grid_for(total)), dim3(256), 0, s, total, limit, (int64_t)n, KK, row_major ? 1 : 0,
+                           src_v, src_c, (const int64_t *)pos.p, cv.p, cr.p, cc.p);
     if (hipGetLastError() != hipSuccess) return nullptr;
     return cgh_matrix_from_entries_device(n, U, row_major ? nullptr : dd.p, cv.p, cr.p, cc.p, layout);
 }
@@ -336,32 +344,38 @@ void mv_ell_symmetric_full_colmajor_sdtint(int n, int max_nnz_row, double *diag,
 void mv_ell_symmetric_upper_colmajor(int n, int max_nnz_row, double *diag, double *ell_values, int *ell_cols, double *x, double *y)
 {
     if (!ensure_ready()) return;
-    for (int s = 0; s < max_nnz_row; ++s)
+    // a stored column <= its row: the reference prints this and returns with y = diag*x + the entries visited so far
+    int64_t stop = -1;
+    for (int s = 0; s < max_nnz_row && stop < 0; ++s)
         for (int i = 0; i < n; ++i) {
             const int c = ell_cols[(size_t)s * n + i];
             if (c != -1 && c <= i) {
                 printf("Error: non-upper element at row=%d, col=%d\n", i, c);
-                return;
+                stop = (int64_t)s * n + i;
+                break;
             }
         }
-    mat_guard g{matrix_from_upper_ell(n, max_nnz_row, diag, ell_values, ell_cols, false, CGH_LAYOUT_ELL)};
+    mat_guard g{matrix_from_upper_ell(n, max_nnz_row, diag, ell_values, ell_cols, false, CGH_LAYOUT_ELL, stop)};
     if (g.m) spmv_host(g.m, x, y);
 }
 
-// reference src/ell.c:168-211.  As for the slot-major variant, a stored column <= its row is reported and y is
-// left untouched (the reference returns with y partially accumulated).
+// reference src/ell.c:168-211.  As for the slot-major variant, a stored column <= its row is reported and y keeps what
+// the reference has accumulated by then: rows before the offending one complete (with their diagonal), that row up
+// to the entry, later rows only what earlier rows scattered into them.
 void mv_ell_symmetric_upper(int n, int max_nnz_row, double *diag, double *ell_values, int *ell_cols, double *x, double *y)
 {
     if (!ensure_ready()) return;
-    for (int i = 0; i < n; ++i)
+    int64_t stop = -1;
+    for (int i = 0; i < n && stop < 0; ++i)
         for (int s = 0; s < max_nnz_row; ++s) {
             const int c = ell_cols[(size_t)i * max_nnz_row + s];
             if (c != -1 && c <= i) {
                 printf("Error: Found a non-upper triangular element in ELL format: row=%d, col=%d\n", i, c);
-                return;
+                stop = (int64_t)i * max_nnz_row + s;
+                break;
             }
         }
-    mat_guard g{matrix_from_upper_ell(n, max_nnz_row, diag, ell_values, ell_cols, true, CGH_LAYOUT_ELL)};
+    mat_guard g{matrix_from_upper_ell(n, max_nnz_row, diag, ell_values, ell_cols, true, CGH_LAYOUT_ELL, stop)};
     if (g.m) spmv_host(g.m, x, y);
 }
 

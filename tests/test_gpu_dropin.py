@@ -157,6 +157,29 @@ def test_spmv_all_formats_bit_exact(api, tag):
     assert np.array_equal(bits(y), bits(want))
 
 
+@pytest.mark.parametrize("tag", ["cylinder_2000", "poisson27_12x10x8"])
+def test_upper_ell_spmv_partial_output_on_malformed_entry(api, tag):
+    """a stored column <= its row: the reference prints an error and returns with y as accumulated so far
+    (ell.c:182-210 row-major, :971-998 slot-major); the device path reproduces that partial y bit for bit"""
+    s, g = inputs(tag), golden(tag)
+    n, Ku = s["n"], int(g["K_upper"])
+    x = np.ascontiguousarray(g["x_probe"])
+    for vals_key, cols_key, oracle_fn, fn, row_major in (
+            ("ell_upcm_vals", "ell_upcm_cols", O.mv_ell_upper_colmajor, api.mv_ell_symmetric_upper_colmajor, False),
+            ("ell_uprm_vals", "ell_uprm_cols", O.mv_ell_upper_rowmajor, api.mv_ell_symmetric_upper, True)):
+        v = np.ascontiguousarray(g[vals_key]); c = np.ascontiguousarray(g[cols_key]).copy()
+        used = np.flatnonzero(c != -1)
+        for where in (used[len(used) // 2], used[0], used[-1]):
+            cc = c.copy()
+            row = where // Ku if row_major else where % n
+            cc[where] = row if where != used[0] else max(row - 1, 0)      # col == row, or col < row
+            want, st = oracle_fn(n, Ku, s["diag"], v, cc, x)
+            assert st != 0
+            y = np.full(n, 7.0)
+            fn(n, Ku, D(s["diag"]), D(v), I(cc), D(x), D(y))
+            assert np.array_equal(bits(y), bits(want)), (vals_key, int(where))
+
+
 @pytest.mark.parametrize("tag", ["cylinder_2000", "cylinder_8000", "poisson7_16", "poisson27_12x10x8"])
 def test_cg_solvers_bit_exact(api, tag):
     s, g = inputs(tag), golden(tag)
