@@ -113,3 +113,28 @@ def test_full_size_256cubed_strict_bit_exact(cga):
     print("\n[256^3 strict] %d iterations in %.2f ms = %.3f ms/iteration" % (iters, rep.solve_ms, rep.solve_ms / iters))
     assert same_bits_nan(hist, np.array(want))
     assert np.array_equal(bits(x.to_host()), bits(xr))
+
+
+def test_random_trials_device(cga, monkeypatch):
+    """random lengths / scales / sign mixes, both the flat (few cells) and the grouped driver"""
+    monkeypatch.setenv("CGH_XSUM_MIN_ROWS", "0")
+    rng = np.random.default_rng(2024)
+    for trial in range(120):
+        n = int(rng.integers(1, 60000)) if trial % 6 else int(rng.integers(530000, 1200000))
+        kind = trial % 4
+        if kind == 0:
+            t = rng.standard_normal(n) ** 2 * 2.0 ** rng.integers(-40, 40)
+        elif kind == 1:
+            t = rng.standard_normal(n) * 2.0 ** rng.integers(-8, 8, n)
+        elif kind == 2:
+            t = np.round(rng.standard_normal(n) * 1024) / 1024      # many exactly representable ties
+        else:
+            t = rng.standard_normal(n) + 1.0
+        dt = cga.DeviceVector.from_host(t); d1 = cga.DeviceVector.from_host(np.ones(n))
+        v = np.zeros(1)
+        cga.binding.check(cga.lib().cgh_dot(dt.ptr, d1.ptr, n, 1, O.D(v)))
+        assert eq(v[0], seq_sum(t)), (trial, n, kind)
+        cga.binding.check(cga.lib().cgh_dot(dt.ptr, dt.ptr, n, 1, O.D(v)))
+        assert eq(v[0], O.lib().orc_vec_dot(O.D(t), O.D(t), n)), (trial, n, kind)
+        cga.binding.check(cga.lib().cgh_l1norm(dt.ptr, n, 1, O.D(v)))
+        assert eq(v[0], O.lib().orc_vec_l1norm(O.D(t), n)), (trial, n, kind)
