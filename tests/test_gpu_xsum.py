@@ -138,3 +138,33 @@ def test_random_trials_device(cga, monkeypatch):
         assert eq(v[0], O.lib().orc_vec_dot(O.D(t), O.D(t), n)), (trial, n, kind)
         cga.binding.check(cga.lib().cgh_l1norm(dt.ptr, n, 1, O.D(v)))
         assert eq(v[0], O.lib().orc_vec_l1norm(O.D(t), n)), (trial, n, kind)
+
+
+@pytest.mark.parametrize("shape", [(17, 17, 17), (20, 20, 11), (32, 32, 8), (64, 64, 33)])
+def test_strict_cg_shapes_around_the_fused_paths(cga, shape):
+    """default thresholds; n odd (scalar SpMV path, odd tail in the cell sums), n even but not a multiple of 128 (no
+    per-cell sums from the SpMV), n a multiple of 128 (everything fused), and a size with the group level: the
+    trajectory and x equal the oracle's bit for bit"""
+    nx, ny, nz = shape
+    n = nx * ny * nz
+    b = cga.DeviceVector(n); x = cga.DeviceVector(n)
+    A = cga.Matrix.poisson(nx, ny, nz, 7, 0x5EED0001, cga.LAYOUT_ELL, b)
+    ev, ec = A.download_ell(); diag = A.download_diag(); bh = b.to_host()
+    ret, xo, traj = O.cg(O.FMT_ELL_FULL, n, diag, 0, ev, ec, None, A.K, bh, 400, 1e-7)
+    rep, hist = cga.cg_solve(A, b, x, max_iter=400, tol=1e-7, strict=1)
+    assert rep.ret == ret and ret > 0
+    assert same_bits_nan(hist, traj) and np.array_equal(bits(x.to_host()), bits(xo))
+
+
+def test_jacobi_graph_replay_matches_eager(cga, monkeypatch):
+    """CGH_GRAPH=1 with the preconditioned kernels (device-side iteration counters)"""
+    nx, ny, nz = 24, 20, 16
+    n = nx * ny * nz
+    b = cga.DeviceVector(n); x = cga.DeviceVector(n); x2 = cga.DeviceVector(n)
+    A = cga.Matrix.poisson(nx, ny, nz, 27, 0x5EED0001, cga.LAYOUT_ELL, b)
+    monkeypatch.setenv("CGH_GRAPH", "0")
+    rep, hist = cga.cg_solve(A, b, x, max_iter=300, tol=1e-8, strict=0, precond=1, check_every=16)
+    monkeypatch.setenv("CGH_GRAPH", "1")
+    rep2, hist2 = cga.cg_solve(A, b, x2, max_iter=300, tol=1e-8, strict=0, precond=1, check_every=16)
+    assert rep.ret > 0 and rep2.ret == rep.ret and same_bits_nan(hist2, hist)
+    assert np.array_equal(bits(x2.to_host()), bits(x.to_host()))
