@@ -101,6 +101,7 @@ def run(args, rank, world, local_rank, shape, seed):
     if rank == 0:
         os.unlink(path)
 
+    p2p = bool(cga.lib().cgh_p2p_connected())
     m = measure(rank, world, shape, seed, args.steps, args.warmup)
     if m is None:
         raise SystemExit("bench_dist: the workload could not be set up on every rank")
@@ -115,8 +116,11 @@ def run(args, rank, world, local_rank, shape, seed):
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%s: 3-D %d-point Poisson %dx%dx%d, %d rows, slot-major ELL, unpreconditioned CG, "
                                    "z-slab row blocks over %d GPUs, p-halo by ncclSend/Recv overlapped with interior SpMV, "
-                                   "2 ncclAllReduce per iteration" % (args.workload, points, nx, ny, nz, m["n"], world),
+                                   "%s" % (args.workload, points, nx, ny, nz, m["n"], world,
+                                           "the 2 scalar all-reduces per iteration as peer-to-peer mailbox kernels over xGMI (p2p.hip)"
+                                           if p2p else "2 ncclAllReduce per iteration"),
                        "rows": m["n"], "nnz_offdiag": m["nnz_off"], "parallelism": "row-block x%d" % world,
+                       "scalar_allreduce": "p2p" if p2p else "rccl",
                        "iter_GBs_algorithmic": (12 * m["nnz_off"] + 96 * m["n"]) / (m["ms_step"] * 1e-3) / 1e9,
                        "residual_l1_half_first_last": m["res"]},
             "roofline": {"bound": "hbm", "kernel": "spmv_ell_r2 (interior + boundary launches, incl. exposed halo wait; slowest rank)",

@@ -107,6 +107,10 @@ def lib():
     L.cgh_comm_init.argtypes = [C.c_int, C.c_int, C.c_char_p]
     L.cgh_comm_destroy.restype = None
     L.cgh_comm_allreduce_f64.argtypes = [dp, C.c_int, C.c_int]
+    L.cgh_p2p_local_handle.argtypes = [C.c_char_p]
+    L.cgh_p2p_connect.argtypes = [C.c_int, C.c_int, C.c_char_p]
+    L.cgh_p2p_disconnect.restype = None
+    L.cgh_p2p_allreduce_f64.argtypes = [dp, C.c_int]
     L.cgh_dist_from_partition.argtypes = [vp]
     L.cgh_dist_from_partition.restype = vp
     L.cgh_dist_poisson.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_int, C.c_int, vp]

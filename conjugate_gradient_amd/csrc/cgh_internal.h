@@ -122,3 +122,6 @@ int cgh_xsum_launch(cgh_xsum *w, int64_t n, const double *a, const double *b, co
                     int iter, double tol, int *done, double *out, hipStream_t s, bool presummed = false);
 double *cgh_xsum_cellsums(cgh_xsum *w);
 int64_t cgh_xsum_cells(const cgh_xsum *w);
+
+// p2p.hip -- scalar all-reduce over peer stores (multi-GPU path); W-interleaved partials in, W sums out
+int cgh_p2p_launch(int W, const double *partials, int count, double *out, hipStream_t s);

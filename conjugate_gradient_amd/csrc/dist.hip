@@ -38,6 +38,7 @@ struct rccl_api {
     ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*GroupStart)() = nullptr;
@@ -48,6 +49,7 @@ struct rccl_api {
     ncclComm_t comm = nullptr;       // all-reduces (compute stream)
     ncclComm_t comm_halo = nullptr;  // neighbour exchange (communication stream)
     int        nranks = 0, rank = -1;
+    bool       p2p = false;          // the scalar all-reduces go through p2p.hip (set up and self-tested in cgh_comm_init)
 } g_rccl;
 
 int load_rccl()
@@ -74,6 +76,7 @@ int load_rccl()
     CGH_SYM(CommInitRank, "ncclCommInitRank")
     CGH_SYM(CommDestroy, "ncclCommDestroy")
     CGH_SYM(AllReduce, "ncclAllReduce")
+    CGH_SYM(AllGather, "ncclAllGather")
     CGH_SYM(Send, "ncclSend")
     CGH_SYM(Recv, "ncclRecv")
     CGH_SYM(GroupStart, "ncclGroupStart")
@@ -300,6 +303,58 @@ int finish_neighbours(cgh_dist *d)
 
 } // namespace
 
+// Peer-to-peer scalar all-reduce: all-gather the mailbox handles over the new communicator, connect, prove the path on
+// sums whose value is known, and let the ranks agree.  Any failure anywhere leaves the RCCL all-reduces in place.
+static bool setup_p2p(int nranks, int rank)
+{
+    hipStream_t s = g_cgh.stream;
+    char        mine[64];
+    bool        ok = cgh_p2p_local_handle(mine) == CGH_OK;
+    char       *d_all = (char *)cgh_alloc(64 * (size_t)nranks + 64);
+    std::vector<char> all(64 * (size_t)nranks);
+    ok = ok && d_all != nullptr && cgh_h2d(d_all + 64 * (size_t)nranks, mine, 64) == CGH_OK;
+    // (every rank takes part in the collectives below whatever its own state, or the others would wait for it)
+    if (d_all) {
+        const ncclResult_t r = g_rccl.AllGather(d_all + 64 * (size_t)nranks, d_all, 64, ncclChar, g_rccl.comm, s);
+        ok = ok && r == ncclSuccess && cgh_d2h(all.data(), d_all, all.size()) == CGH_OK;
+    }
+    ok = ok && cgh_p2p_connect(nranks, rank, all.data()) == CGH_OK;
+    double *buf = (double *)cgh_alloc(sizeof(double) * 8);
+    double  flag = ok && buf ? 1.0 : 0.0;
+    // barrier + agreement #1: everybody connected (mailboxes zeroed) before anybody sends
+    if (buf) {
+        bool c = cgh_h2d(buf, &flag, sizeof flag) == CGH_OK &&
+                 g_rccl.AllReduce(buf, buf + 1, 1, ncclDouble, ncclMin, g_rccl.comm, s) == ncclSuccess &&
+                 cgh_d2h(&flag, buf + 1, sizeof flag) == CGH_OK;
+        if (!c) flag = 0.0;
+    }
+    if (flag == 1.0) {
+        // self-test: rank r contributes (r+1)*k/2 and -(r+1)*k in round k; the sums are exact small numbers
+        for (int k = 1; k <= 6 && ok; ++k) {
+            const double v[2] = {(rank + 1) * k * 0.5, -(double)(rank + 1) * k};
+            const double tot = nranks * (nranks + 1) / 2.0;
+            double       got[2] = {0.0, 0.0};
+            ok = cgh_h2d(buf, v, sizeof v) == CGH_OK && cgh_p2p_launch(2, buf, 1, buf + 2, s) == CGH_OK &&
+                 cgh_d2h(got, buf + 2, sizeof got) == CGH_OK && got[0] == tot * k * 0.5 && got[1] == -tot * k;
+        }
+        ok = ok && cgh_p2p_error() == 0;
+        // agreement #2: everybody passed
+        flag = ok ? 1.0 : 0.0;
+        bool c = cgh_h2d(buf, &flag, sizeof flag) == CGH_OK &&
+                 g_rccl.AllReduce(buf, buf + 1, 1, ncclDouble, ncclMin, g_rccl.comm, s) == ncclSuccess &&
+                 cgh_d2h(&flag, buf + 1, sizeof flag) == CGH_OK;
+        if (!c) flag = 0.0;
+    }
+    cgh_free(buf);
+    cgh_free(d_all);
+    if (flag != 1.0) {
+        cgh_p2p_disconnect();
+        if (getenv("CGH_P2P_VERBOSE")) fprintf(stderr, "[cg_hip] rank %d: peer-to-peer all-reduce not used (%s)\n", rank, cgh_last_error());
+        return false;
+    }
+    return true;
+}
+
 extern "C" {
 
 // ------------------------------------------------------------------------------------------ communicator
@@ -332,6 +387,9 @@ int cgh_comm_init(int nranks, int rank, const char id_bytes[256])
     CGH_NCCL(g_rccl.CommInitRank(&g_rccl.comm_halo, nranks, id1, rank));
     g_rccl.nranks = nranks;
     g_rccl.rank = rank;
+    g_rccl.p2p = false;
+    const char *env = getenv("CGH_P2P");
+    if (!(env && atoi(env) == 0) && nranks <= 16) g_rccl.p2p = setup_p2p(nranks, rank);
     return CGH_OK;
 }
 
@@ -364,6 +422,8 @@ int cgh_comm_allreduce_f64(double *h_vals, int count, int op)
 
 void cgh_comm_destroy(void)
 {
+    cgh_p2p_disconnect();
+    g_rccl.p2p = false;
     if (g_rccl.comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(g_rccl.comm);
     if (g_rccl.comm_halo && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(g_rccl.comm_halo);
     g_rccl.comm = g_rccl.comm_halo = nullptr;
@@ -595,12 +655,22 @@ int cgh_dist_iterate(cgh_dist *d, int count, int time_kernels)
         rc = spmv_ranges(d, false, true, true, &cnt, s, d->done);   // boundary rows
         if (rc) return rc;
         if (time_kernels) CGH_HIP(hipEventRecord(d->kev.back(), s));
-        hipLaunchKernelGGL(reduce_local<1>, dim3(1), dim3(CGH_BLOCK), 0, s, (const double *)d->partA, cnt, d->gs_local);
-        CGH_NCCL(g_rccl.AllReduce(d->gs_local, d->gs, 1, ncclDouble, ncclSum, g_rccl.comm, s));
+        if (g_rccl.p2p) {  // one kernel: local sum, peer stores, wait, sum over ranks
+            rc = cgh_p2p_launch(1, d->partA, cnt, d->gs, s);
+            if (rc) return rc;
+        } else {
+            hipLaunchKernelGGL(reduce_local<1>, dim3(1), dim3(CGH_BLOCK), 0, s, (const double *)d->partA, cnt, d->gs_local);
+            CGH_NCCL(g_rccl.AllReduce(d->gs_local, d->gs, 1, ncclDouble, ncclSum, g_rccl.comm, s));
+        }
         hipLaunchKernelGGL((cg_update_r<2, 3>), dim3(d->vgrid), dim3(CGH_BLOCK), 0, s, nl, d->r, (const double *)d->Ap,
                            (const double *)nullptr, 0, d->partB, d->hist, iter, (const int *)d->done, 0, (const double *)d->gs);
-        hipLaunchKernelGGL(reduce_local<2>, dim3(2), dim3(CGH_BLOCK), 0, s, (const double *)d->partB, d->vgrid, d->gs_local + 1);
-        CGH_NCCL(g_rccl.AllReduce(d->gs_local + 1, d->gs + 1, 2, ncclDouble, ncclSum, g_rccl.comm, s));
+        if (g_rccl.p2p) {
+            rc = cgh_p2p_launch(2, d->partB, d->vgrid, d->gs + 1, s);
+            if (rc) return rc;
+        } else {
+            hipLaunchKernelGGL(reduce_local<2>, dim3(2), dim3(CGH_BLOCK), 0, s, (const double *)d->partB, d->vgrid, d->gs_local + 1);
+            CGH_NCCL(g_rccl.AllReduce(d->gs_local + 1, d->gs + 1, 2, ncclDouble, ncclSum, g_rccl.comm, s));
+        }
         hipLaunchKernelGGL((cg_update_xp<2, 3>), dim3(d->vgrid), dim3(CGH_BLOCK), 0, s, nl, d->x, (const double *)d->r, d->p,
                            (const double *)nullptr, 0, d->hist, iter, d->tol, d->done, 0, (const double *)d->gs);
         CGH_HIP(hipGetLastError());
@@ -620,6 +690,10 @@ int cgh_dist_poll(cgh_dist *d, int *done_iter, int *queued)
     CGH_HIP(hipMemcpyAsync(v, d->done, sizeof(int) * 4, hipMemcpyDeviceToHost, s));
     CGH_HIP(hipStreamSynchronize(s));
     CGH_HIP(hipStreamSynchronize(g_cgh.comm_stream));
+    if (g_rccl.p2p && cgh_p2p_error()) {
+        cgh_set_error("cgh_dist_poll: a peer's reduction message did not arrive (timeout in the peer-to-peer all-reduce)");
+        return CGH_ECOMM;
+    }
     if (done_iter) *done_iter = (g_rccl.comm && d->nranks > 1) ? v[3] : v[0];
     if (queued) *queued = d->queued;
     return CGH_OK;

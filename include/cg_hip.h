@@ -187,6 +187,17 @@ int cgh_comm_preload(void);   /* dlopen RCCL now (call before another copy of li
 int cgh_comm_unique_id(char out_256_bytes[256]);
 int cgh_comm_init(int nranks, int rank, const char id_256_bytes[256]);
 void cgh_comm_destroy(void);
+/* Peer-to-peer scalar all-reduce (p2p.hip): cgh_comm_init sets it up by itself over the RCCL communicator (handles
+ * all-gathered, self-test, all ranks agree; CGH_P2P=0 disables) and cgh_dist_iterate then uses it for the two
+ * reductions of an iteration instead of ncclAllReduce.  The pieces are exported for hosts that bootstrap differently
+ * and for tests: every rank takes its mailbox handle (64 bytes), the handles travel by any means, every rank connects;
+ * a barrier must separate the connects from the first all-reduce. */
+int  cgh_p2p_local_handle(char out_64_bytes[64]);
+int  cgh_p2p_connect(int nranks, int rank, const char *handles_nranks_x_64_bytes);
+void cgh_p2p_disconnect(void);
+int  cgh_p2p_connected(void);
+int  cgh_p2p_error(void);                          /* 1 after a timed-out wait (results are NaN from then on) */
+int  cgh_p2p_allreduce_f64(double *h_vals, int count);   /* 1 or 2 host doubles, summed in rank order */
 /* launcher helper: all-reduce up to 64 host doubles over the ranks (op 0 sum, 1 max, 2 min); one value = a barrier */
 int cgh_comm_allreduce_f64(double *h_vals, int count, int op);
 

@@ -120,3 +120,26 @@ def test_rccl_loop_single_rank(cga):
     cga.lib().cgh_comm_destroy()
     with pytest.raises(RuntimeError):
         cga.comm_allreduce([1.0])
+
+
+def test_p2p_allreduce_two_processes_one_gpu(tmp_path):
+    """the peer-to-peer scalar all-reduce (p2p.hip) between two PROCESSES: hipIpc mailboxes, tagged 64-bit words, the
+    waits inside the kernel.  Both ranks share the one GPU of the test box (RCCL refuses that, peer stores do not care);
+    400 exchanges per rank with deliberate skew."""
+    import os
+    import subprocess
+    import sys
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "p2p_worker.py")
+    procs = [subprocess.Popen([sys.executable, worker, str(r), "2", str(tmp_path)], stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=150)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append((p.returncode, out))
+    for r, (code, out) in enumerate(outs):
+        assert code == 0 and "rank %d ok" % r in out, out[-2000:]
