@@ -46,6 +46,32 @@ def barrier():
     cga.comm_allreduce([0.0], "sum")
 
 
+def validate_p2p(rank, world, seed):
+    """The peer-to-peer all-reduce passed the library's self-test at start-up; here the SOLVER runs 12 iterations of a
+    small partitioned problem with it and 12 without (RCCL all-reduces): the residual histories must agree to rounding
+    on every rank, or the benchmark goes on with RCCL.  Returns the path in force."""
+    L = cga.lib()
+    if not L.cgh_p2p_connected():
+        return "rccl"
+    shape = (64, 64, 8 * world)
+    nl = shape[0] * shape[1] * 8
+    hists = []
+    for on in (1, 0):
+        L.cgh_comm_set_p2p(on)
+        b = cga.DeviceVector(nl); x = cga.DeviceVector(nl)
+        D = cga.DistRank.poisson(shape[0], shape[1], shape[2], 7, seed, world, rank, b)
+        D.start(b, x, -1.0, 14)
+        D.iterate(12, 0)
+        cga.check(L.cgh_sync())
+        hists.append(D.history(0, 13))
+        D.free()
+    a, r = hists
+    ok = bool(np.all(np.isfinite(a[:, :2]))) and bool(np.all(r[:, :2] != 0.0)) and float(np.max(np.abs(a[:, :2] - r[:, :2]) / np.abs(r[:, :2]))) < 1e-9
+    ok = cga.comm_allreduce([1.0 if ok else 0.0], "min")[0] == 1.0
+    L.cgh_comm_set_p2p(1 if ok else 0)
+    return "p2p" if ok else "rccl (p2p disagreed with the RCCL all-reduce in a 12-iteration check)"
+
+
 def measure(rank, world, shape, seed, steps, warmup):
     """One partitioned workload: generate this rank's z-slab, warm up, time `steps` iterations (barrier + device sync on
     both sides, MAX over ranks).  Returns a dict on every rank, or None if some rank could not set the problem up."""
@@ -101,7 +127,8 @@ def run(args, rank, world, local_rank, shape, seed):
     if rank == 0:
         os.unlink(path)
 
-    p2p = bool(cga.lib().cgh_p2p_connected())
+    path = validate_p2p(rank, world, seed)
+    p2p = path == "p2p"
     m = measure(rank, world, shape, seed, args.steps, args.warmup)
     if m is None:
         raise SystemExit("bench_dist: the workload could not be set up on every rank")
@@ -120,7 +147,7 @@ def run(args, rank, world, local_rank, shape, seed):
                                            "the 2 scalar all-reduces per iteration as peer-to-peer mailbox kernels over xGMI (p2p.hip)"
                                            if p2p else "2 ncclAllReduce per iteration"),
                        "rows": m["n"], "nnz_offdiag": m["nnz_off"], "parallelism": "row-block x%d" % world,
-                       "scalar_allreduce": "p2p" if p2p else "rccl",
+                       "scalar_allreduce": path,
                        "iter_GBs_algorithmic": (12 * m["nnz_off"] + 96 * m["n"]) / (m["ms_step"] * 1e-3) / 1e9,
                        "residual_l1_half_first_last": m["res"]},
             "roofline": {"bound": "hbm", "kernel": "spmv_ell_r2 (interior + boundary launches, incl. exposed halo wait; slowest rank)",

@@ -420,6 +420,14 @@ int cgh_comm_allreduce_f64(double *h_vals, int count, int op)
     return rc;
 }
 
+// Use (1) or bypass (0) the peer-to-peer scalar all-reduce for the following solves; it can only be switched on if
+// cgh_comm_init connected it.  Every rank must make the same choice.  Returns the state now in force.
+int cgh_comm_set_p2p(int on)
+{
+    g_rccl.p2p = on != 0 && cgh_p2p_connected() != 0;
+    return g_rccl.p2p ? 1 : 0;
+}
+
 void cgh_comm_destroy(void)
 {
     cgh_p2p_disconnect();

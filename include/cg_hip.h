@@ -196,6 +196,7 @@ int  cgh_p2p_local_handle(char out_64_bytes[64]);
 int  cgh_p2p_connect(int nranks, int rank, const char *handles_nranks_x_64_bytes);
 void cgh_p2p_disconnect(void);
 int  cgh_p2p_connected(void);
+int  cgh_comm_set_p2p(int on);                    /* use / bypass it for the following solves (all ranks alike); returns the state */
 int  cgh_p2p_error(void);                          /* 1 after a timed-out wait (results are NaN from then on) */
 int  cgh_p2p_allreduce_f64(double *h_vals, int count);   /* 1 or 2 host doubles, summed in rank order */
 /* launcher helper: all-reduce up to 64 host doubles over the ranks (op 0 sum, 1 max, 2 min); one value = a barrier */
