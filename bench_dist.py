@@ -101,12 +101,13 @@ def measure(rank, world, shape, seed, steps, warmup):
     dt, spmv_ms = cga.comm_allreduce([dt, spmv_ms], "max")      # slowest rank
     nnz_total = cga.comm_allreduce([float(D.nnz_offdiag)], "sum")[0]   # exact: far below 2^53
     hist = D.history(0, cap)
-    assert np.all(np.isfinite(hist[1:, 0])), "non-finite residual: the iteration did not run"
+    finite = bool(np.all(np.isfinite(hist[1:, 0]))) and cga.lib().cgh_p2p_error() == 0
+    finite = cga.comm_allreduce([1.0 if finite else 0.0], "min")[0] == 1.0     # one verdict for all ranks
     n = nx * ny * nz
     nnz_off = int(nnz_total)
     alg_spmv = 12 * nnz_off + 24 * n
     D.free()
-    return {"n": n, "nnz_off": nnz_off, "alg_spmv": alg_spmv, "dt": dt, "spmv_ms": spmv_ms, "steps": steps,
+    return {"finite": finite, "n": n, "nnz_off": nnz_off, "alg_spmv": alg_spmv, "dt": dt, "spmv_ms": spmv_ms, "steps": steps,
             "ms_step": dt / steps * 1e3, "achieved": alg_spmv / (spmv_ms * 1e-3) / 1e9,
             "res": [float(hist[0, 0]), float(hist[-1, 0])]}
 
@@ -132,6 +133,13 @@ def run(args, rank, world, local_rank, shape, seed):
     m = measure(rank, world, shape, seed, args.steps, args.warmup)
     if m is None:
         raise SystemExit("bench_dist: the workload could not be set up on every rank")
+    if not m["finite"] and p2p:
+        # the peer-to-peer reductions misbehaved under load after passing both checks: measure again over RCCL
+        cga.lib().cgh_comm_set_p2p(0)
+        p2p, path = False, "rccl (the run with p2p reductions produced non-finite residuals)"
+        m = measure(rank, world, shape, seed, args.steps, args.warmup)
+    if m is None or not m["finite"]:
+        raise SystemExit("bench_dist: non-finite residual: the iteration did not run")
     extra = None
     if args.workload == "p7_256" and not args.no_config4:
         extra = measure(rank, world, (512, 512, 512, 27), seed, min(args.steps, 20), min(args.warmup, 3))
@@ -155,7 +163,7 @@ def run(args, rank, world, local_rank, shape, seed):
                          "frac": m["achieved"] / (HBM_PEAK_GBS * world), "bytes_per_launch": int(m["alg_spmv"]),
                          "ms_per_launch": m["spmv_ms"], "traffic": None},
         }
-        if extra is not None:
+        if extra is not None and extra["finite"]:
             out["config4"] = {"workload": "p27_512: 3-D 27-point Poisson 512^3, %d rows, %d off-diagonals, z-slabs over %d GPUs"
                                           % (extra["n"], extra["nnz_off"], world),
                               "value": extra["steps"] / extra["dt"], "unit": "iterations/s", "steps": extra["steps"],
