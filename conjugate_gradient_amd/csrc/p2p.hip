@@ -47,7 +47,8 @@ __global__ __launch_bounds__(256) void p2p_allreduce_kernel(int W, const double 
         if (threadIdx.x == 0) mine[w] = v;
     }
     __syncthreads();
-    const int slot = (int)(seq % P2P_SLOTS), words = 2 * W, t = threadIdx.x;
+    const int  slot = (int)(seq % P2P_SLOTS), words = 2 * W, t = threadIdx.x;
+    const bool broken = *err != 0;  // an earlier exchange timed out: keep sending (the peers may still be fine), never wait again
     if (t < n * words) {
         const int      peer = t / words, wi = t % words;
         const uint64_t bits = (uint64_t)__double_as_longlong(mine[wi >> 1]);
@@ -59,7 +60,7 @@ __global__ __launch_bounds__(256) void p2p_allreduce_kernel(int W, const double 
         const uint64_t *q = box + ((size_t)(slot * P2P_MAX_RANKS + peer) * P2P_WORDS + wi);
         const long long t0 = wall_clock64();
         uint64_t        v = 0;
-        for (;;) {
+        while (!broken) {
             v = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             if ((unsigned)(v >> 32) == seq) break;
             if (wall_clock64() - t0 > 1000000000ll) {  // 10 s at the 100 MHz constant clock
@@ -77,7 +78,7 @@ __global__ __launch_bounds__(256) void p2p_allreduce_kernel(int W, const double 
             const uint64_t bits = ((uint64_t)halves[r * P2P_WORDS + 2 * t + 1] << 32) | halves[r * P2P_WORDS + 2 * t];
             s += __longlong_as_double((long long)bits);
         }
-        out[t] = *err ? NAN : s;
+        out[t] = (broken || *err) ? NAN : s;
     }
 }
 

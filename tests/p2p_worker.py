@@ -11,6 +11,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import conjugate_gradient_amd as cga  # noqa: E402
 
 rank, nranks, d = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
+mode = sys.argv[4] if len(sys.argv) > 4 else "normal"     # "mute": rank 1 never sends (timeout test)
 
 
 def publish(name, data):
@@ -44,6 +45,21 @@ handles = b"".join(collect("handle", 64))
 cga.check(L.cgh_p2p_connect(nranks, rank, handles), "connect")
 publish("ready%d" % rank, b"1")          # barrier: every mailbox is zeroed and mapped before anybody sends
 collect("ready", 1)
+if mode == "mute":
+    if rank == 1:
+        time.sleep(16)                     # connected, mailbox mapped, but silent
+        print("rank 1 ok", flush=True)
+        sys.exit(0)
+    v = np.array([1.0])
+    t0 = time.time()
+    rc = L.cgh_p2p_allreduce_f64(v.ctypes.data_as(C.POINTER(C.c_double)), 1)
+    waited = time.time() - t0
+    assert rc != 0 and 8.0 < waited < 14.0 and L.cgh_p2p_error() == 1, (rc, waited)
+    t0 = time.time()
+    rc = L.cgh_p2p_allreduce_f64(v.ctypes.data_as(C.POINTER(C.c_double)), 1)   # broken: no second 10 s wait
+    assert rc != 0 and time.time() - t0 < 1.0
+    print("rank 0 ok", flush=True)
+    sys.exit(0)
 tot = nranks * (nranks + 1) / 2.0
 for k in range(1, 201):
     v = np.array([(rank + 1) * k * 0.5, -(rank + 1.0) * k])

@@ -122,15 +122,17 @@ def test_rccl_loop_single_rank(cga):
         cga.comm_allreduce([1.0])
 
 
-def test_p2p_allreduce_two_processes_one_gpu(tmp_path):
+@pytest.mark.parametrize("mode", ["normal", "mute"])
+def test_p2p_allreduce_two_processes_one_gpu(tmp_path, mode):
     """the peer-to-peer scalar all-reduce (p2p.hip) between two PROCESSES: hipIpc mailboxes, tagged 64-bit words, the
     waits inside the kernel.  Both ranks share the one GPU of the test box (RCCL refuses that, peer stores do not care);
-    400 exchanges per rank with deliberate skew."""
+    400 exchanges per rank with deliberate skew.  "mute": rank 1 connects and stays silent -- rank 0's wait must end
+    after its 10 s limit with an error instead of hanging, and later exchanges must not wait again."""
     import os
     import subprocess
     import sys
     worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "p2p_worker.py")
-    procs = [subprocess.Popen([sys.executable, worker, str(r), "2", str(tmp_path)], stdout=subprocess.PIPE,
+    procs = [subprocess.Popen([sys.executable, worker, str(r), "2", str(tmp_path), mode], stdout=subprocess.PIPE,
                               stderr=subprocess.STDOUT, text=True) for r in range(2)]
     outs = []
     for p in procs:
