@@ -72,7 +72,7 @@ def validate_p2p(rank, world, seed):
     return "p2p" if ok else "rccl (p2p disagreed with the RCCL all-reduce in a 12-iteration check)"
 
 
-def measure(rank, world, shape, seed, steps, warmup):
+def measure(rank, world, shape, seed, steps, warmup, p2p_in_force):
     """One partitioned workload: generate this rank's z-slab, warm up, time `steps` iterations (barrier + device sync on
     both sides, MAX over ranks).  Returns a dict on every rank, or None if some rank could not set the problem up."""
     nx, ny, nz, points = shape
@@ -87,6 +87,7 @@ def measure(rank, world, shape, seed, steps, warmup):
         ok = 0
     if cga.comm_allreduce([ok], "min")[0] == 0:
         return None
+    halo = "p2p" if cga.lib().cgh_dist_halo_is_p2p(D.h) else "rccl"
     cap = warmup + steps + 1
     D.start(b, x, -1.0, cap)                    # tol < 0: never converges, every step does full work
     D.iterate(warmup, 0)
@@ -101,13 +102,13 @@ def measure(rank, world, shape, seed, steps, warmup):
     dt, spmv_ms = cga.comm_allreduce([dt, spmv_ms], "max")      # slowest rank
     nnz_total = cga.comm_allreduce([float(D.nnz_offdiag)], "sum")[0]   # exact: far below 2^53
     hist = D.history(0, cap)
-    finite = bool(np.all(np.isfinite(hist[1:, 0]))) and cga.lib().cgh_p2p_error() == 0
+    finite = bool(np.all(np.isfinite(hist[1:, 0]))) and (not p2p_in_force or cga.lib().cgh_p2p_error() == 0)
     finite = cga.comm_allreduce([1.0 if finite else 0.0], "min")[0] == 1.0     # one verdict for all ranks
     n = nx * ny * nz
     nnz_off = int(nnz_total)
     alg_spmv = 12 * nnz_off + 24 * n
     D.free()
-    return {"finite": finite, "n": n, "nnz_off": nnz_off, "alg_spmv": alg_spmv, "dt": dt, "spmv_ms": spmv_ms, "steps": steps,
+    return {"finite": finite, "halo": halo, "n": n, "nnz_off": nnz_off, "alg_spmv": alg_spmv, "dt": dt, "spmv_ms": spmv_ms, "steps": steps,
             "ms_step": dt / steps * 1e3, "achieved": alg_spmv / (spmv_ms * 1e-3) / 1e9,
             "res": [float(hist[0, 0]), float(hist[-1, 0])]}
 
@@ -130,19 +131,19 @@ def run(args, rank, world, local_rank, shape, seed):
 
     path = validate_p2p(rank, world, seed)
     p2p = path == "p2p"
-    m = measure(rank, world, shape, seed, args.steps, args.warmup)
+    m = measure(rank, world, shape, seed, args.steps, args.warmup, p2p)
     if m is None:
         raise SystemExit("bench_dist: the workload could not be set up on every rank")
     if not m["finite"] and p2p:
         # the peer-to-peer reductions misbehaved under load after passing both checks: measure again over RCCL
         cga.lib().cgh_comm_set_p2p(0)
         p2p, path = False, "rccl (the run with p2p reductions produced non-finite residuals)"
-        m = measure(rank, world, shape, seed, args.steps, args.warmup)
+        m = measure(rank, world, shape, seed, args.steps, args.warmup, p2p)
     if m is None or not m["finite"]:
         raise SystemExit("bench_dist: non-finite residual: the iteration did not run")
     extra = None
     if args.workload == "p7_256" and not args.no_config4:
-        extra = measure(rank, world, (512, 512, 512, 27), seed, min(args.steps, 20), min(args.warmup, 3))
+        extra = measure(rank, world, (512, 512, 512, 27), seed, min(args.steps, 20), min(args.warmup, 3), p2p)
     if rank == 0:
         out = {
             "metric": "CG iterations/sec (SpMV achieved HBM GB/s in roofline)",
@@ -150,12 +151,14 @@ def run(args, rank, world, local_rank, shape, seed):
             "warmup": args.warmup, "ms_per_step": m["ms_step"], "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%s: 3-D %d-point Poisson %dx%dx%d, %d rows, slot-major ELL, unpreconditioned CG, "
-                                   "z-slab row blocks over %d GPUs, p-halo by ncclSend/Recv overlapped with interior SpMV, "
-                                   "%s" % (args.workload, points, nx, ny, nz, m["n"], world,
-                                           "the 2 scalar all-reduces per iteration as peer-to-peer mailbox kernels over xGMI (p2p.hip)"
-                                           if p2p else "2 ncclAllReduce per iteration"),
+                                   "z-slab row blocks over %d GPUs, %s" % (
+                                       args.workload, points, nx, ny, nz, m["n"], world,
+                                       "p-halo by peer-to-peer deposits over xGMI overlapped with the interior SpMV, the 2 scalar "
+                                       "all-reduces per iteration as peer-to-peer mailbox kernels (RCCL: bootstrap and fallback)"
+                                       if p2p else
+                                       "p-halo by ncclSend/Recv overlapped with the interior SpMV, 2 ncclAllReduce per iteration"),
                        "rows": m["n"], "nnz_offdiag": m["nnz_off"], "parallelism": "row-block x%d" % world,
-                       "scalar_allreduce": path,
+                       "scalar_allreduce": path, "halo_exchange": m["halo"],
                        "iter_GBs_algorithmic": (12 * m["nnz_off"] + 96 * m["n"]) / (m["ms_step"] * 1e-3) / 1e9,
                        "residual_l1_half_first_last": m["res"]},
             "roofline": {"bound": "hbm", "kernel": "spmv_ell_r2 (interior + boundary launches, incl. exposed halo wait; slowest rank)",

@@ -108,6 +108,10 @@ def lib():
     L.cgh_comm_destroy.restype = None
     L.cgh_comm_allreduce_f64.argtypes = [dp, C.c_int, C.c_int]
     L.cgh_p2p_local_handle.argtypes = [C.c_char_p]
+    L.cgh_comm_init_local.argtypes = [C.c_int, C.c_int]
+    L.cgh_dist_halo_descriptor.argtypes = [vp, C.c_char_p]
+    L.cgh_dist_halo_connect.argtypes = [vp, C.c_char_p]
+    L.cgh_dist_halo_is_p2p.argtypes = [vp]
     L.cgh_p2p_connect.argtypes = [C.c_int, C.c_int, C.c_char_p]
     L.cgh_p2p_disconnect.restype = None
     L.cgh_p2p_allreduce_f64.argtypes = [dp, C.c_int]

@@ -176,6 +176,15 @@ inline int grid_for(int64_t work) { return cgh_stream_grid((work + 255) / 256, 8
 
 } // namespace
 
+// one neighbour's transfer as the peer-to-peer halo kernels see it
+struct halo_xfer {
+    double       *dst;     // push: the neighbour's deposit region for me (slot 0), as mapped here; pull: p + n_loc + recv_off
+    const double *src;     // pull: my deposit region for this neighbour (slot 0); push: unused
+    uint64_t     *flag;    // push: the neighbour's flag word for me; pull: my flag word for this neighbour
+    const int    *idx;     // push: rows to send, NULL when they are contiguous from `start`
+    int64_t       start, cnt;
+};
+
 // ------------------------------------------------------------------------------------------ per-rank state
 struct cgh_dist_nb {
     int      rank = -1;
@@ -204,6 +213,14 @@ struct cgh_dist {
     std::vector<hipEvent_t> kev;
     // group driver only
     double **d_locals = nullptr, **d_outs = nullptr;
+    // peer-to-peer halo (optional, see "peer-to-peer halo" below): the neighbours deposit their boundary entries here
+    char    *hbuf = nullptr;                       // fine-grained, IPC-shared: [flags][per neighbour: 2 slots x recv_cnt doubles]
+    std::vector<size_t> h_off;                     // per neighbour: byte offset of its region in hbuf
+    std::vector<void *> h_opened;                  // per neighbour: its hbuf as mapped here (hipIpcOpenMemHandle)
+    struct halo_xfer *d_push = nullptr, *d_pull = nullptr;   // device: one descriptor per neighbour
+    int     *d_herr = nullptr;                     // device: 1 after a timed-out wait
+    bool     halo_p2p = false;
+    unsigned hseq = 0;                             // halo exchanges so far
 };
 
 namespace {
@@ -301,6 +318,198 @@ int finish_neighbours(cgh_dist *d)
     return CGH_OK;
 }
 
+
+// ------------------------------------------------------------------------------------------ peer-to-peer halo
+// The same exchange without a library: rank g stores its boundary entries of p straight into a deposit buffer of the
+// neighbour (fine-grained device memory shared through hipIpc), fences, and raises the neighbour's flag word to the
+// sequence number of the exchange; the neighbour waits for the flag and copies the deposit into the halo tail of its
+// own p with ordinary local stores (so its SpMV reads coherent, cacheable memory).  Two deposit slots alternate: a rank
+// cannot start exchange k+2 before every neighbour has consumed exchange k (it needs their reduction messages of
+// iteration k+1, which they send after their SpMV of k+1).  One workgroup per neighbour on either side.
+constexpr size_t HALO_FLAG_BYTES = 256;           // 16 flag words + padding
+constexpr int    HALO_MAX_NB = 16;
+constexpr size_t HALO_DESC_BYTES = 512;
+struct halo_desc {                                // what a rank tells the others about its deposit buffer
+    char    handle[64];
+    int32_t rank, n;
+    struct {
+        int32_t src, flag_idx;
+        int64_t off, cnt;
+    } e[HALO_MAX_NB];
+};
+static_assert(sizeof(halo_desc) <= HALO_DESC_BYTES, "descriptor size");
+
+__global__ __launch_bounds__(1024) void halo_push(const halo_xfer *__restrict__ xf, const double *__restrict__ p, unsigned seq)
+{
+    const halo_xfer a = xf[blockIdx.x];
+    double         *dst = a.dst + (size_t)(seq & 1u) * (size_t)a.cnt;
+    for (int64_t k = threadIdx.x; k < a.cnt; k += 1024) dst[k] = p[a.idx ? (int64_t)a.idx[k] : a.start + k];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence_system();  // the deposit before the flag
+        __hip_atomic_store(a.flag, (uint64_t)seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+__global__ __launch_bounds__(1024) void halo_pull(const halo_xfer *__restrict__ xf, unsigned seq, int *err)
+{
+    const halo_xfer a = xf[blockIdx.x];
+    __shared__ int  ok;
+    if (threadIdx.x == 0) {
+        ok = 1;
+        if (*err != 0) {
+            ok = 0;  // an earlier wait timed out: never wait again
+        } else {
+            const long long t0 = wall_clock64();
+            // (the flag only grows; a neighbour cannot be more than one exchange ahead, and that one uses the other slot)
+            while (__hip_atomic_load(a.flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < (uint64_t)seq) {
+                if (wall_clock64() - t0 > 1000000000ll) {  // 10 s
+                    atomicExch(err, 1);
+                    ok = 0;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(2);
+            }
+        }
+    }
+    __syncthreads();
+    if (!ok) return;
+    __threadfence_system();
+    const uint64_t *src = reinterpret_cast<const uint64_t *>(a.src + (size_t)(seq & 1u) * (size_t)a.cnt);
+    for (int64_t k = threadIdx.x; k < a.cnt; k += 1024)  // loads that bypass every cache: the words were written by a peer
+        a.dst[k] = __longlong_as_double((long long)__hip_atomic_load(src + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+}
+
+void halo_release(cgh_dist *d)
+{
+    for (void *p : d->h_opened)
+        if (p) (void)hipIpcCloseMemHandle(p);
+    d->h_opened.clear();
+    cgh_free(d->d_push);
+    cgh_free(d->d_pull);
+    cgh_free(d->d_herr);
+    d->d_push = d->d_pull = nullptr;
+    d->d_herr = nullptr;
+    if (d->hbuf) (void)hipFree(d->hbuf);
+    d->hbuf = nullptr;
+    d->halo_p2p = false;
+}
+
+int halo_descriptor(cgh_dist *d, char *out)
+{
+    if ((int)d->nbs.size() > HALO_MAX_NB) {
+        cgh_set_error("peer-to-peer halo: more than %d neighbours", HALO_MAX_NB);
+        return CGH_EINVAL;
+    }
+    if (!d->hbuf) {
+        size_t bytes = HALO_FLAG_BYTES;
+        d->h_off.clear();
+        for (const cgh_dist_nb &nb : d->nbs) {
+            d->h_off.push_back(bytes);
+            bytes += ((size_t)(2 * nb.recv_cnt) * sizeof(double) + 255) & ~(size_t)255;
+        }
+        void *p = nullptr;
+        if (hipExtMallocWithFlags(&p, bytes, hipDeviceMallocFinegrained) != hipSuccess) {
+            (void)hipGetLastError();
+            CGH_HIP(hipMalloc(&p, bytes));
+        }
+        d->hbuf = (char *)p;
+        CGH_HIP(hipMemset(d->hbuf, 0, bytes));
+        CGH_HIP(hipDeviceSynchronize());
+    }
+    halo_desc h;
+    memset(&h, 0, sizeof h);
+    hipIpcMemHandle_t ih;
+    CGH_HIP(hipIpcGetMemHandle(&ih, d->hbuf));
+    memcpy(h.handle, &ih, 64);
+    h.rank = d->rank;
+    h.n = (int32_t)d->nbs.size();
+    for (size_t i = 0; i < d->nbs.size(); ++i) {
+        h.e[i].src = d->nbs[i].rank;
+        h.e[i].flag_idx = (int32_t)i;
+        h.e[i].off = (int64_t)d->h_off[i];
+        h.e[i].cnt = d->nbs[i].recv_cnt;
+    }
+    memset(out, 0, HALO_DESC_BYTES);
+    memcpy(out, &h, sizeof h);
+    return CGH_OK;
+}
+
+// all: nranks x 512 bytes, rank order.  Maps every neighbour's deposit buffer and builds the transfer lists.
+int halo_connect(cgh_dist *d, const char *all)
+{
+    if (!d->hbuf) return CGH_EINVAL;
+    const size_t nnb = d->nbs.size();
+    std::vector<halo_xfer> push(nnb ? nnb : 1), pull(nnb ? nnb : 1);
+    d->h_opened.assign(nnb, nullptr);
+    for (size_t i = 0; i < nnb; ++i) {
+        const cgh_dist_nb &nb = d->nbs[i];
+        halo_desc          h;
+        memcpy(&h, all + HALO_DESC_BYTES * (size_t)nb.rank, sizeof h);
+        int at = -1;
+        for (int k = 0; k < h.n && k < HALO_MAX_NB; ++k)
+            if (h.e[k].src == d->rank) at = k;
+        if (h.rank != nb.rank || at < 0 || h.e[at].cnt != nb.send_cnt) {
+            cgh_set_error("peer-to-peer halo: rank %d does not expect %lld entries from rank %d", nb.rank, (long long)nb.send_cnt, d->rank);
+            return CGH_ECOMM;
+        }
+        hipIpcMemHandle_t ih;
+        memcpy(&ih, h.handle, 64);
+        void *base = nullptr;
+        if (nb.rank == d->rank) {
+            base = d->hbuf;
+        } else {
+            const hipError_t e = hipIpcOpenMemHandle(&base, ih, hipIpcMemLazyEnablePeerAccess);
+            if (e != hipSuccess) {
+                (void)hipGetLastError();
+                cgh_set_error("peer-to-peer halo: hipIpcOpenMemHandle(rank %d) -> %s", nb.rank, hipGetErrorString(e));
+                return CGH_ECOMM;
+            }
+            d->h_opened[i] = base;
+        }
+        push[i].dst = reinterpret_cast<double *>((char *)base + h.e[at].off);
+        push[i].src = nullptr;
+        push[i].flag = reinterpret_cast<uint64_t *>(base) + h.e[at].flag_idx;
+        push[i].idx = nb.contig_start >= 0 ? nullptr : nb.d_send_idx;
+        push[i].start = nb.contig_start >= 0 ? nb.contig_start : 0;
+        push[i].cnt = nb.send_cnt;
+        pull[i].dst = nullptr;  // p is allocated per solve: filled in by halo_bind()
+        pull[i].src = reinterpret_cast<const double *>(d->hbuf + d->h_off[i]);
+        pull[i].flag = reinterpret_cast<uint64_t *>(d->hbuf) + i;
+        pull[i].idx = nullptr;
+        pull[i].start = nb.recv_off;
+        pull[i].cnt = nb.recv_cnt;
+    }
+    d->d_push = (halo_xfer *)cgh_alloc(sizeof(halo_xfer) * (nnb ? nnb : 1));
+    d->d_pull = (halo_xfer *)cgh_alloc(sizeof(halo_xfer) * (nnb ? nnb : 1));
+    d->d_herr = (int *)cgh_alloc(sizeof(int));
+    if (!d->d_push || !d->d_pull || !d->d_herr) return CGH_ENOMEM;
+    int rc = cgh_h2d(d->d_push, push.data(), sizeof(halo_xfer) * (nnb ? nnb : 1));
+    if (rc == CGH_OK) rc = cgh_h2d(d->d_pull, pull.data(), sizeof(halo_xfer) * (nnb ? nnb : 1));
+    if (rc == CGH_OK) rc = cgh_memset(d->d_herr, 0, sizeof(int));
+    if (rc) return rc;
+    d->hseq = 0;
+    d->halo_p2p = true;
+    return CGH_OK;
+}
+
+// the pull descriptors point into this solve's p
+__global__ void halo_bind_kernel(halo_xfer *pull, int n, double *halo_base)
+{
+    if ((int)threadIdx.x < n) pull[threadIdx.x].dst = halo_base + pull[threadIdx.x].start;
+}
+
+int exchange_p2p(cgh_dist *d, hipStream_t c)
+{
+    if (d->nbs.empty()) return CGH_OK;
+    const unsigned seq = ++d->hseq;
+    const unsigned nnb = (unsigned)d->nbs.size();
+    hipLaunchKernelGGL(halo_push, dim3(nnb), dim3(1024), 0, c, (const halo_xfer *)d->d_push, (const double *)d->p, seq);
+    hipLaunchKernelGGL(halo_pull, dim3(nnb), dim3(1024), 0, c, (const halo_xfer *)d->d_pull, seq, d->d_herr);
+    CGH_HIP(hipGetLastError());
+    return CGH_OK;
+}
+
 } // namespace
 
 // Peer-to-peer scalar all-reduce: all-gather the mailbox handles over the new communicator, connect, prove the path on
@@ -353,6 +562,38 @@ static bool setup_p2p(int nranks, int rank)
         return false;
     }
     return true;
+}
+
+// With RCCL up and the peer-to-peer path agreed on, connect the halo of a new cgh_dist the same way: descriptors
+// all-gathered, every rank maps its neighbours, a min-reduce decides for all.  Collective.
+static void auto_connect_halo(cgh_dist *d)
+{
+    const char *env = getenv("CGH_P2P_HALO");
+    if (!g_rccl.comm || !g_rccl.p2p || (env && atoi(env) == 0) || g_rccl.nranks != d->nranks) return;
+    hipStream_t       s = g_cgh.stream;
+    const size_t      n = (size_t)d->nranks;
+    std::vector<char> all(HALO_DESC_BYTES * n), mine(HALO_DESC_BYTES);
+    bool              ok = halo_descriptor(d, mine.data()) == CGH_OK;
+    char             *d_all = (char *)cgh_alloc(HALO_DESC_BYTES * (n + 1));
+    double           *flag = (double *)cgh_alloc(sizeof(double) * 2);
+    ok = ok && d_all && flag && cgh_h2d(d_all + HALO_DESC_BYTES * n, mine.data(), HALO_DESC_BYTES) == CGH_OK;
+    if (d_all) {
+        const ncclResult_t r = g_rccl.AllGather(d_all + HALO_DESC_BYTES * n, d_all, HALO_DESC_BYTES, ncclChar, g_rccl.comm, s);
+        ok = ok && r == ncclSuccess && cgh_d2h(all.data(), d_all, all.size()) == CGH_OK;
+    }
+    ok = ok && halo_connect(d, all.data()) == CGH_OK;
+    double v = ok ? 1.0 : 0.0;
+    if (flag) {
+        const bool c = cgh_h2d(flag, &v, sizeof v) == CGH_OK &&
+                       g_rccl.AllReduce(flag, flag + 1, 1, ncclDouble, ncclMin, g_rccl.comm, s) == ncclSuccess &&
+                       cgh_d2h(&v, flag + 1, sizeof v) == CGH_OK;
+        if (!c) v = 0.0;
+    } else {
+        v = 0.0;
+    }
+    cgh_free(d_all);
+    cgh_free(flag);
+    if (v != 1.0) halo_release(d);  // somebody could not: everybody keeps the RCCL send/recv
 }
 
 extern "C" {
@@ -420,10 +661,52 @@ int cgh_comm_allreduce_f64(double *h_vals, int count, int op)
     return rc;
 }
 
+// Ranks without RCCL: the scalar reductions and the halo exchange both go peer to peer (the caller connects the mailboxes
+// with cgh_p2p_connect and every cgh_dist with cgh_dist_halo_connect, e.g. through files).  This is also how several
+// ranks can share ONE GPU, which RCCL refuses -- the test harness of the multi-rank loop.
+int cgh_comm_init_local(int nranks, int rank)
+{
+    CGH_REQUIRE_READY(CGH_ENODEV);
+    if (nranks < 1 || rank < 0 || rank >= nranks || !cgh_p2p_connected()) {
+        cgh_set_error("cgh_comm_init_local: connect the peer-to-peer mailboxes first (cgh_p2p_connect)");
+        return CGH_EINVAL;
+    }
+    if (g_rccl.comm) return CGH_EINVAL;
+    g_rccl.nranks = nranks;
+    g_rccl.rank = rank;
+    g_rccl.p2p = true;
+    return CGH_OK;
+}
+
+// This rank's deposit buffer for the peer-to-peer halo as a 512-byte descriptor; every rank's descriptor (rank order)
+// goes to cgh_dist_halo_connect on every rank, then a barrier, then cgh_dist_start.
+int cgh_dist_halo_descriptor(cgh_dist *d, char out_512_bytes[512])
+{
+    CGH_REQUIRE_READY(CGH_ENODEV);
+    if (!d || !out_512_bytes) return CGH_EINVAL;
+    return halo_descriptor(d, out_512_bytes);
+}
+
+int cgh_dist_halo_connect(cgh_dist *d, const char *descriptors)
+{
+    CGH_REQUIRE_READY(CGH_ENODEV);
+    if (!d || !descriptors) return CGH_EINVAL;
+    const int rc = halo_connect(d, descriptors);
+    if (rc != CGH_OK) {
+        const bool had = d->hbuf != nullptr;
+        (void)had;
+        d->halo_p2p = false;
+    }
+    return rc;
+}
+
+int cgh_dist_halo_is_p2p(const cgh_dist *d) { return d && d->halo_p2p ? 1 : 0; }
+
 // Use (1) or bypass (0) the peer-to-peer scalar all-reduce for the following solves; it can only be switched on if
 // cgh_comm_init connected it.  Every rank must make the same choice.  Returns the state now in force.
 int cgh_comm_set_p2p(int on)
 {
+    if (!g_rccl.comm) return g_rccl.p2p ? 1 : 0;  // without RCCL there is nothing to fall back to
     g_rccl.p2p = on != 0 && cgh_p2p_connected() != 0;
     return g_rccl.p2p ? 1 : 0;
 }
@@ -485,6 +768,7 @@ cgh_dist *cgh_dist_from_partition(const cgh_partition *P)
         cgh_dist_free(d);
         return nullptr;
     }
+    auto_connect_halo(d);
     return d;
 }
 
@@ -565,6 +849,7 @@ cgh_dist *cgh_dist_poisson(int nx, int ny, int nz, int points, uint64_t seed, in
         nb.recv_cnt = nxy;
         d->nbs.push_back(nb);
     }
+    auto_connect_halo(d);
     return d;
 }
 
@@ -582,6 +867,7 @@ void cgh_dist_free(cgh_dist *d)
     cgh_free(d->mat.vals);
     cgh_free(d->mat.cols);
     cgh_ell_dict_free(&d->mat);
+    halo_release(d);
     delete d;
 }
 
@@ -605,8 +891,9 @@ int cgh_dist_start(cgh_dist *d, const double *d_b, double *d_x, double tol, int 
 {
     CGH_REQUIRE_READY(CGH_ENODEV);
     if (!d || !d_b || !d_x || capacity < 1) return CGH_EINVAL;
-    if (!g_rccl.comm || g_rccl.nranks != d->nranks || g_rccl.rank != d->rank) {
-        cgh_set_error("cgh_dist_start: no RCCL communicator for rank %d of %d (call cgh_comm_init first)", d->rank, d->nranks);
+    const bool no_library = g_rccl.p2p && (d->halo_p2p || d->nbs.empty());   // nothing left for RCCL to do
+    if ((!g_rccl.comm && !no_library) || g_rccl.nranks != d->nranks || g_rccl.rank != d->rank) {
+        cgh_set_error("cgh_dist_start: no communicator for rank %d of %d (call cgh_comm_init first)", d->rank, d->nranks);
         return CGH_ECOMM;
     }
     int rc = alloc_solver_state(d, capacity);
@@ -619,13 +906,20 @@ int cgh_dist_start(cgh_dist *d, const double *d_b, double *d_x, double tol, int 
     CGH_HIP(hipMemsetAsync(d->done, 0, sizeof(int) * 4, s));
     CGH_HIP(hipMemsetAsync(d_x, 0, sizeof(double) * (size_t)nl, s));
     CGH_HIP(hipMemsetAsync(d->p, 0, sizeof(double) * (size_t)(nl + d->n_halo), s));  // x0 = 0, halo of x0 = 0
+    if (d->halo_p2p && !d->nbs.empty())
+        hipLaunchKernelGGL(halo_bind_kernel, dim3(1), dim3(64), 0, s, d->d_pull, (int)d->nbs.size(), d->p + nl);
     int cnt = 0;
     rc = spmv_ranges(d, true, true, false, &cnt, s, nullptr);  // Ap = A*0, as the reference computes it (cg.c:441)
     if (rc) return rc;
     hipLaunchKernelGGL(cg_init_rp, dim3(d->vgrid), dim3(CGH_BLOCK), 0, s, nl, d_b, (const double *)d->Ap, d->r, d->p, d->partB);
-    hipLaunchKernelGGL(reduce_local<2>, dim3(2), dim3(CGH_BLOCK), 0, s, (const double *)d->partB, d->vgrid, d->gs_local + 1);
-    CGH_HIP(hipGetLastError());
-    CGH_NCCL(g_rccl.AllReduce(d->gs_local + 1, d->gs + 1, 2, ncclDouble, ncclSum, g_rccl.comm, s));
+    if (g_rccl.p2p) {
+        rc = cgh_p2p_launch(2, d->partB, d->vgrid, d->gs + 1, s);
+        if (rc) return rc;
+    } else {
+        hipLaunchKernelGGL(reduce_local<2>, dim3(2), dim3(CGH_BLOCK), 0, s, (const double *)d->partB, d->vgrid, d->gs_local + 1);
+        CGH_HIP(hipGetLastError());
+        CGH_NCCL(g_rccl.AllReduce(d->gs_local + 1, d->gs + 1, 2, ncclDouble, ncclSum, g_rccl.comm, s));
+    }
     hipLaunchKernelGGL(finish_init_dist, dim3(1), dim3(1), 0, s, (const double *)d->gs, d->hist);
     CGH_HIP(hipGetLastError());
     return CGH_OK;
@@ -645,7 +939,7 @@ int cgh_dist_iterate(cgh_dist *d, int count, int time_kernels)
         // halo exchange of p on the communication stream, behind the kernel that last wrote p
         CGH_HIP(hipEventRecord(d->ev_p, s));
         CGH_HIP(hipStreamWaitEvent(c, d->ev_p, 0));
-        int rc = exchange_rccl(d, c);
+        int rc = (g_rccl.p2p && d->halo_p2p) ? exchange_p2p(d, c) : exchange_rccl(d, c);
         if (rc) return rc;
         CGH_HIP(hipEventRecord(d->ev_halo, c));
         if (time_kernels) {
@@ -698,6 +992,13 @@ int cgh_dist_poll(cgh_dist *d, int *done_iter, int *queued)
     CGH_HIP(hipMemcpyAsync(v, d->done, sizeof(int) * 4, hipMemcpyDeviceToHost, s));
     CGH_HIP(hipStreamSynchronize(s));
     CGH_HIP(hipStreamSynchronize(g_cgh.comm_stream));
+    if (g_rccl.p2p && d->halo_p2p && d->d_herr) {
+        int he = 0;
+        if (cgh_d2h(&he, d->d_herr, sizeof he) != CGH_OK || he) {
+            cgh_set_error("cgh_dist_poll: a neighbour's halo did not arrive (timeout in the peer-to-peer exchange)");
+            return CGH_ECOMM;
+        }
+    }
     if (g_rccl.p2p && cgh_p2p_error()) {
         cgh_set_error("cgh_dist_poll: a peer's reduction message did not arrive (timeout in the peer-to-peer all-reduce)");
         return CGH_ECOMM;

@@ -196,6 +196,7 @@ int  cgh_p2p_local_handle(char out_64_bytes[64]);
 int  cgh_p2p_connect(int nranks, int rank, const char *handles_nranks_x_64_bytes);
 void cgh_p2p_disconnect(void);
 int  cgh_p2p_connected(void);
+int  cgh_comm_init_local(int nranks, int rank);   /* ranks without RCCL (mailboxes connected by the caller); several may share one GPU */
 int  cgh_comm_set_p2p(int on);                    /* use / bypass it for the following solves (all ranks alike); returns the state */
 int  cgh_p2p_error(void);                          /* 1 after a timed-out wait (results are NaN from then on) */
 int  cgh_p2p_allreduce_f64(double *h_vals, int count);   /* 1 or 2 host doubles, summed in rank order */
@@ -225,6 +226,13 @@ int cgh_dist_group_iterate(cgh_dist **ranks, int nranks, int count);
 int     cgh_dist_width(const cgh_dist *d);
 int64_t cgh_dist_halo(const cgh_dist *d);
 int     cgh_dist_download_local(const cgh_dist *d, double *diag, double *ell_vals, int *ell_cols);
+/* Peer-to-peer halo exchange (no library in the loop): each rank deposits its boundary entries of p straight into a
+ * buffer of the neighbour (hipIpc) and raises a flag; see dist.hip.  With an RCCL communicator whose peer-to-peer path
+ * is up, cgh_dist_from_partition / cgh_dist_poisson connect it by themselves (collectively: every rank must create
+ * its cgh_dist at the same point); otherwise the host moves the 512-byte descriptors (rank order), then a barrier. */
+int     cgh_dist_halo_descriptor(cgh_dist *d, char out_512_bytes[512]);
+int     cgh_dist_halo_connect(cgh_dist *d, const char *descriptors_nranks_x_512_bytes);
+int     cgh_dist_halo_is_p2p(const cgh_dist *d);
 
 /* ---- timing helpers (benchmarks) ---------------------------------------- */
 /* Launch `reps` back-to-back SpMVs and return the average kernel time in ms (HIP events on the launch stream). */

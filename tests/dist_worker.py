@@ -1,0 +1,75 @@
+"""One rank of the multi-PROCESS test of the distributed CG loop (tests/test_gpu_dist.py): all ranks share the one GPU
+of the test box, so the transport is the peer-to-peer one throughout (mailbox all-reduce + deposit-buffer halo); handles
+and descriptors travel through files.  python dist_worker.py <rank> <nranks> <dir> <nx> <ny> <nz> <points> <max_iter> <tol>
+Writes hist_<rank>.npy and x_<rank>.npy."""
+import ctypes as C
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import conjugate_gradient_amd as cga  # noqa: E402
+
+rank, nranks, d = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
+nx, ny, nz, points, max_iter = (int(v) for v in sys.argv[4:9])
+tol = float(sys.argv[9])
+
+
+def publish(name, data):
+    with open(os.path.join(d, name + ".tmp"), "wb") as f:
+        f.write(data)
+    os.replace(os.path.join(d, name + ".tmp"), os.path.join(d, name))
+
+
+def collect(prefix, size):
+    out = []
+    for r in range(nranks):
+        path = os.path.join(d, "%s%d" % (prefix, r))
+        t0 = time.time()
+        while not os.path.exists(path):
+            if time.time() - t0 > 90:
+                raise SystemExit("rank %d: %s never appeared" % (rank, path))
+            time.sleep(0.01)
+        with open(path, "rb") as f:
+            data = f.read()
+        assert len(data) == size, (path, len(data))
+        out.append(data)
+    return b"".join(out)
+
+
+cga.init(0)
+L = cga.lib()
+buf = C.create_string_buffer(64)
+cga.check(L.cgh_p2p_local_handle(buf), "local_handle")
+publish("handle%d" % rank, buf.raw)
+cga.check(L.cgh_p2p_connect(nranks, rank, collect("handle", 64)), "p2p connect")
+cga.check(L.cgh_comm_init_local(nranks, rank), "comm_init_local")
+
+nl = nx * ny * (nz * (rank + 1) // nranks - nz * rank // nranks)
+b = cga.DeviceVector(nl); x = cga.DeviceVector(nl)
+D = cga.DistRank.poisson(nx, ny, nz, points, 0x5EED0001, nranks, rank, b)
+desc = C.create_string_buffer(512)
+cga.check(L.cgh_dist_halo_descriptor(D.h, desc), "halo descriptor")
+publish("desc%d" % rank, desc.raw)
+cga.check(L.cgh_dist_halo_connect(D.h, collect("desc", 512)), "halo connect")
+assert L.cgh_dist_halo_is_p2p(D.h) == 1
+publish("ready%d" % rank, b"1")          # barrier: every mailbox / deposit buffer is zeroed and mapped before anybody sends
+collect("ready", 1)
+
+D.start(b, x, tol, max_iter)
+done, queued = 0, 0
+while queued < max_iter - 1 and not done:
+    D.iterate(min(7, max_iter - 1 - queued), 0)
+    done, queued = D.poll()
+    if rank == nranks - 1:
+        time.sleep(0.002)                  # skew: the last rank is always late
+iters = done if done else queued
+np.save(os.path.join(d, "hist_%d.npy" % rank), D.history(0, iters + 1))
+np.save(os.path.join(d, "x_%d.npy" % rank), x.to_host())
+publish("finished%d" % rank, b"1")         # nobody unmaps a buffer a peer may still write to
+collect("finished", 1)
+D.free()
+L.cgh_p2p_disconnect()
+print("rank %d ok done=%d" % (rank, done), flush=True)

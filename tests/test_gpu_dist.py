@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 import foamio
-from gpu_common import bits, golden, inputs
+from gpu_common import bits, golden, inputs, same_bits_nan
 
 pytestmark = pytest.mark.gpu
 
@@ -145,3 +145,38 @@ def test_p2p_allreduce_two_processes_one_gpu(tmp_path, mode):
         outs.append((p.returncode, out))
     for r, (code, out) in enumerate(outs):
         assert code == 0 and "rank %d ok" % r in out, out[-2000:]
+
+
+@pytest.mark.parametrize("G,shape,points", [(2, (32, 24, 20), 7), (4, (32, 24, 20), 7), (8, (32, 24, 20), 7),
+                                            (3, (12, 10, 8), 27), (8, (12, 10, 8), 27)])
+def test_multi_process_loop_on_one_gpu(tmp_path, G, shape, points):
+    """The distributed CG loop with G PROCESSES (one rank each, all on the test box's single GPU): peer-to-peer scalar
+    all-reduces and peer-to-peer halo exchange between real processes, host threads running at their own pace, the last
+    rank deliberately late.  Every rank's history equals every other's bit for bit and the golden trajectory of the
+    reference within 1e-10; the gathered x equals the golden solution within the solver tolerance."""
+    import os
+    import subprocess
+    import sys
+    tag = "poisson7_32x24x20" if points == 7 else "poisson27_12x10x8"
+    g = golden(tag)
+    mi, tol = int(g["max_iter"]), float(g["tol"])
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "dist_worker.py")
+    args = [str(v) for v in (*shape, points, mi, tol)]
+    procs = [subprocess.Popen([sys.executable, worker, str(r), str(G), str(tmp_path)] + args, stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True) for r in range(G)]
+    outs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=170)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append((p.returncode, out))
+    for r, (code, out) in enumerate(outs):
+        assert code == 0 and "rank %d ok" % r in out, out[-3000:]
+    hists = [np.load(os.path.join(tmp_path, "hist_%d.npy" % r)) for r in range(G)]
+    xs = np.concatenate([np.load(os.path.join(tmp_path, "x_%d.npy" % r)) for r in range(G)])
+    for h in hists[1:]:
+        assert same_bits_nan(h, hists[0])
+    _check_against_golden(hists[0].shape[0], hists[0], xs, g)
