@@ -72,6 +72,33 @@ def validate_p2p(rank, world, seed):
     return "p2p" if ok else "rccl (p2p disagreed with the RCCL all-reduce in a 12-iteration check)"
 
 
+def probe_transports(rank, world, shape, seed):
+    """Both transports on the benchmark's own matrix, 60 timed iterations each (after 10): the timed run then uses the
+    faster one, and the line reports both.  Returns (use_p2p, {"p2p_us_per_iter": .., "rccl_us_per_iter": ..})."""
+    L = cga.lib()
+    nx, ny, nz, points = shape
+    nl = nx * ny * (nz * (rank + 1) // world - nz * rank // world)
+    us = {}
+    for name, on in (("p2p", 1), ("rccl", 0)):
+        L.cgh_comm_set_p2p(on)
+        b = cga.DeviceVector(nl); x = cga.DeviceVector(nl)
+        D = cga.DistRank.poisson(nx, ny, nz, points, seed, world, rank, b)
+        D.start(b, x, -1.0, 72)
+        D.iterate(10, 0)
+        cga.check(L.cgh_sync())
+        barrier()
+        t0 = time.perf_counter()
+        D.iterate(60, 0)
+        cga.check(L.cgh_sync())
+        barrier()
+        dt = cga.comm_allreduce([time.perf_counter() - t0], "max")[0]
+        us[name + "_us_per_iter"] = dt / 60 * 1e6
+        D.free()
+    use = us["p2p_us_per_iter"] <= us["rccl_us_per_iter"]
+    L.cgh_comm_set_p2p(1 if use else 0)
+    return use, us
+
+
 def measure(rank, world, shape, seed, steps, warmup, p2p_in_force):
     """One partitioned workload: generate this rank's z-slab, warm up, time `steps` iterations (barrier + device sync on
     both sides, MAX over ranks).  Returns a dict on every rank, or None if some rank could not set the problem up."""
@@ -131,6 +158,11 @@ def run(args, rank, world, local_rank, shape, seed):
 
     path = validate_p2p(rank, world, seed)
     p2p = path == "p2p"
+    probe = None
+    if p2p:
+        p2p, probe = probe_transports(rank, world, shape, seed)
+        if not p2p:
+            path = "rccl (faster than p2p in the probe)"
     m = measure(rank, world, shape, seed, args.steps, args.warmup, p2p)
     if m is None:
         raise SystemExit("bench_dist: the workload could not be set up on every rank")
@@ -158,7 +190,7 @@ def run(args, rank, world, local_rank, shape, seed):
                                        if p2p else
                                        "p-halo by ncclSend/Recv overlapped with the interior SpMV, 2 ncclAllReduce per iteration"),
                        "rows": m["n"], "nnz_offdiag": m["nnz_off"], "parallelism": "row-block x%d" % world,
-                       "scalar_allreduce": path, "halo_exchange": m["halo"],
+                       "scalar_allreduce": path, "halo_exchange": m["halo"], "transport_probe": probe,
                        "iter_GBs_algorithmic": (12 * m["nnz_off"] + 96 * m["n"]) / (m["ms_step"] * 1e-3) / 1e9,
                        "residual_l1_half_first_last": m["res"]},
             "roofline": {"bound": "hbm", "kernel": "spmv_ell_r2 (interior + boundary launches, incl. exposed halo wait; slowest rank)",
