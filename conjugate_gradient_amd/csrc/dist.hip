@@ -325,8 +325,10 @@ int finish_neighbours(cgh_dist *d)
 // sequence number of the exchange; the neighbour waits for the flag and copies the deposit into the halo tail of its
 // own p with ordinary local stores (so its SpMV reads coherent, cacheable memory).  Two deposit slots alternate: a rank
 // cannot start exchange k+2 before every neighbour has consumed exchange k (it needs their reduction messages of
-// iteration k+1, which they send after their SpMV of k+1).  One workgroup per neighbour on either side.
-constexpr size_t HALO_FLAG_BYTES = 256;           // 16 flag words + padding
+// iteration k+1, which they send after their SpMV of k+1).  Four workgroups per neighbour on either side, each with its
+// own quarter of the entries and its own flag word.
+constexpr int    HALO_SEG = 4;                    // workgroups (and flag words) per neighbour: each moves a quarter
+constexpr size_t HALO_FLAG_BYTES = 1024;          // 16 neighbours x 4 flag words + padding
 constexpr int    HALO_MAX_NB = 16;
 constexpr size_t HALO_DESC_BYTES = 512;
 struct halo_desc {                                // what a rank tells the others about its deposit buffer
@@ -341,19 +343,23 @@ static_assert(sizeof(halo_desc) <= HALO_DESC_BYTES, "descriptor size");
 
 __global__ __launch_bounds__(1024) void halo_push(const halo_xfer *__restrict__ xf, const double *__restrict__ p, unsigned seq)
 {
-    const halo_xfer a = xf[blockIdx.x];
+    const halo_xfer a = xf[blockIdx.x / HALO_SEG];
+    const int       seg = blockIdx.x % HALO_SEG;
+    const int64_t   per = (a.cnt + HALO_SEG - 1) / HALO_SEG, k0 = seg * per, k1 = k0 + per < a.cnt ? k0 + per : a.cnt;
     double         *dst = a.dst + (size_t)(seq & 1u) * (size_t)a.cnt;
-    for (int64_t k = threadIdx.x; k < a.cnt; k += 1024) dst[k] = p[a.idx ? (int64_t)a.idx[k] : a.start + k];
+    for (int64_t k = k0 + threadIdx.x; k < k1; k += 1024) dst[k] = p[a.idx ? (int64_t)a.idx[k] : a.start + k];
     __syncthreads();
     if (threadIdx.x == 0) {
-        __threadfence_system();  // the deposit before the flag
-        __hip_atomic_store(a.flag, (uint64_t)seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __threadfence_system();  // this segment's deposit before its flag
+        __hip_atomic_store(a.flag + seg, (uint64_t)seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
 __global__ __launch_bounds__(1024) void halo_pull(const halo_xfer *__restrict__ xf, unsigned seq, int *err)
 {
-    const halo_xfer a = xf[blockIdx.x];
+    const halo_xfer a = xf[blockIdx.x / HALO_SEG];
+    const int       seg = blockIdx.x % HALO_SEG;
+    const int64_t   per = (a.cnt + HALO_SEG - 1) / HALO_SEG, k0 = seg * per, k1 = k0 + per < a.cnt ? k0 + per : a.cnt;
     __shared__ int  ok;
     if (threadIdx.x == 0) {
         ok = 1;
@@ -362,7 +368,7 @@ __global__ __launch_bounds__(1024) void halo_pull(const halo_xfer *__restrict__ 
         } else {
             const long long t0 = wall_clock64();
             // (the flag only grows; a neighbour cannot be more than one exchange ahead, and that one uses the other slot)
-            while (__hip_atomic_load(a.flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < (uint64_t)seq) {
+            while (__hip_atomic_load(a.flag + seg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < (uint64_t)seq) {
                 if (wall_clock64() - t0 > 1000000000ll) {  // 10 s
                     atomicExch(err, 1);
                     ok = 0;
@@ -376,7 +382,7 @@ __global__ __launch_bounds__(1024) void halo_pull(const halo_xfer *__restrict__ 
     if (!ok) return;
     __threadfence_system();
     const uint64_t *src = reinterpret_cast<const uint64_t *>(a.src + (size_t)(seq & 1u) * (size_t)a.cnt);
-    for (int64_t k = threadIdx.x; k < a.cnt; k += 1024)  // loads that bypass every cache: the words were written by a peer
+    for (int64_t k = k0 + threadIdx.x; k < k1; k += 1024)  // loads that bypass every cache: the words were written by a peer
         a.dst[k] = __longlong_as_double((long long)__hip_atomic_load(src + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
 }
 
@@ -469,13 +475,13 @@ int halo_connect(cgh_dist *d, const char *all)
         }
         push[i].dst = reinterpret_cast<double *>((char *)base + h.e[at].off);
         push[i].src = nullptr;
-        push[i].flag = reinterpret_cast<uint64_t *>(base) + h.e[at].flag_idx;
+        push[i].flag = reinterpret_cast<uint64_t *>(base) + (size_t)h.e[at].flag_idx * HALO_SEG;
         push[i].idx = nb.contig_start >= 0 ? nullptr : nb.d_send_idx;
         push[i].start = nb.contig_start >= 0 ? nb.contig_start : 0;
         push[i].cnt = nb.send_cnt;
         pull[i].dst = nullptr;  // p is allocated per solve: filled in by halo_bind()
         pull[i].src = reinterpret_cast<const double *>(d->hbuf + d->h_off[i]);
-        pull[i].flag = reinterpret_cast<uint64_t *>(d->hbuf) + i;
+        pull[i].flag = reinterpret_cast<uint64_t *>(d->hbuf) + i * HALO_SEG;
         pull[i].idx = nullptr;
         pull[i].start = nb.recv_off;
         pull[i].cnt = nb.recv_cnt;
@@ -503,7 +509,7 @@ int exchange_p2p(cgh_dist *d, hipStream_t c)
 {
     if (d->nbs.empty()) return CGH_OK;
     const unsigned seq = ++d->hseq;
-    const unsigned nnb = (unsigned)d->nbs.size();
+    const unsigned nnb = (unsigned)d->nbs.size() * HALO_SEG;
     hipLaunchKernelGGL(halo_push, dim3(nnb), dim3(1024), 0, c, (const halo_xfer *)d->d_push, (const double *)d->p, seq);
     hipLaunchKernelGGL(halo_pull, dim3(nnb), dim3(1024), 0, c, (const halo_xfer *)d->d_pull, seq, d->d_herr);
     CGH_HIP(hipGetLastError());
