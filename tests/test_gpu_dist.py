@@ -180,3 +180,40 @@ def test_multi_process_loop_on_one_gpu(tmp_path, G, shape, points):
     for h in hists[1:]:
         assert same_bits_nan(h, hists[0])
     _check_against_golden(hists[0].shape[0], hists[0], xs, g)
+
+
+def test_multi_process_loop_larger_halo(tmp_path, cga):
+    """4 processes on one GPU, 128x128x64 7-point (1M rows, halo planes of 16384 entries, 50 iterations): every rank's
+    history identical, and equal to the single-GPU throughput-mode trajectory of the same matrix within rounding"""
+    import os
+    import subprocess
+    import sys
+    G, shape, iters = 4, (128, 128, 64), 50
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "dist_worker.py")
+    args = [str(v) for v in (*shape, 7, iters + 1, -1.0)]
+    procs = [subprocess.Popen([sys.executable, worker, str(r), str(G), str(tmp_path)] + args, stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True) for r in range(G)]
+    n = shape[0] * shape[1] * shape[2]
+    b = cga.DeviceVector(n); x = cga.DeviceVector(n)
+    A = cga.Matrix.poisson(*shape, 7, 0x5EED0001, cga.LAYOUT_ELL, b)
+    rep, hist = cga.cg_solve(A, b, x, fixed_iters=iters, strict=0)
+    outs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=170)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append((p.returncode, out))
+    for r, (code, out) in enumerate(outs):
+        assert code == 0 and "rank %d ok" % r in out, out[-3000:]
+    hists = [np.load(os.path.join(tmp_path, "hist_%d.npy" % r)) for r in range(G)]
+    xs = np.concatenate([np.load(os.path.join(tmp_path, "x_%d.npy" % r)) for r in range(G)])
+    for h in hists[1:]:
+        assert same_bits_nan(h, hists[0])
+    assert hists[0].shape[0] == iters + 1
+    rel = np.abs(hists[0][:, :2] - hist[:, :2]) / np.abs(hist[:, :2])
+    assert rel.max() < 1e-9
+    xr = x.to_host()
+    assert np.abs(xs - xr).max() <= 1e-9 * np.abs(xr).max()
