@@ -112,6 +112,7 @@ def lib():
     L.cgh_dist_halo_descriptor.argtypes = [vp, C.c_char_p]
     L.cgh_dist_halo_connect.argtypes = [vp, C.c_char_p]
     L.cgh_dist_halo_is_p2p.argtypes = [vp]
+    L.cgh_dist_loopback.argtypes = [vp]
     L.cgh_p2p_connect.argtypes = [C.c_int, C.c_int, C.c_char_p]
     L.cgh_p2p_disconnect.restype = None
     L.cgh_p2p_allreduce_f64.argtypes = [dp, C.c_int]
@@ -390,6 +391,10 @@ class DistRank:
         d = np.empty(self.n_loc); ev = np.empty(self.n_loc * self.K); ec = np.empty(self.n_loc * self.K, dtype=np.int32)
         check(lib().cgh_dist_download_local(self.h, _D(d), _D(ev), _I(ec)), "dist_download_local")
         return d, ev, ec
+
+    def loopback(self):
+        """one-GPU timing harness: this inner slab becomes its own two neighbours (cgh_dist_loopback)"""
+        check(lib().cgh_dist_loopback(self.h), "cgh_dist_loopback")
 
     def start(self, b, x, tol, capacity):
         self._keep = (b, x)

@@ -13,6 +13,13 @@
 // xGMI is point-to-point (a dedicated link per GPU pair), so the neighbour exchange is plain send/recv pairs,
 // not a ring; the all-reduces carry 8-16 bytes and are pure latency.
 //
+// That is the FALLBACK.  When the ranks can map each other's memory (hipIpc over xGMI; cgh_comm_init tries it and all
+// ranks agree), RCCL only bootstraps and an iteration is four kernels on ONE stream with no event and no library call:
+//     s: SpMV interior rows ; SpMV boundary rows, halo columns read from the deposit buffer the neighbours wrote into ;
+//        dist_update_r  (prologue: p.Ap all-reduced through the peers' mailboxes) ;
+//        dist_update_xp (prologue: r.r, |r|_1 all-reduced ; epilogue: boundary rows of the new p pushed to the neighbours)
+// (halo_ll.h, dist_kernels.h; measured: a cross-stream event costs ~11 us each way, a small kernel ~5 us.)
+//
 // A second driver (cgh_dist_group_*) runs G ranks inside ONE process on ONE device with the exchange and the
 // reductions done by device kernels: it exists so that every kernel, index list and buffer layout of this
 // path is exercised by the single-GPU test box; only the RCCL calls themselves are not.
@@ -22,12 +29,18 @@
 #include <vector>
 
 #include "cg_kernels.h"
+#include "dist_kernels.h"
 #include "partition.h"
 
 int cgh_launch_spmv_ell_range(const cgh_matrix *m, const double *x, double *y, double *dot_partials, int *grid_out,
                               const int *done, hipStream_t s, int64_t rb, int64_t re);
 int cgh_launch_spmv_ell_range2(const cgh_matrix *m, const double *x, double *y, double *dot_partials, int *grid_out,
                                const int *done, hipStream_t s, int64_t rb, int64_t re, int64_t rb2, int64_t re2);
+
+bool cgh_spmv_ell_halo_capable(const cgh_matrix *m, const double *x, double *y, int64_t rb, int64_t re, int64_t rb2, int64_t re2);
+int cgh_launch_spmv_ell_halo(const cgh_matrix *m, const double *x, double *y, double *dot_partials, int *grid_out,
+                             const int *done, hipStream_t s, int64_t rb, int64_t re, int64_t rb2, int64_t re2,
+                             const cgh_ll_halo *hl);
 
 // ------------------------------------------------------------------------------------- RCCL, loaded lazily
 namespace {
@@ -50,6 +63,7 @@ struct rccl_api {
     ncclComm_t comm_halo = nullptr;  // neighbour exchange (communication stream)
     int        nranks = 0, rank = -1;
     bool       p2p = false;          // the scalar all-reduces go through p2p.hip (set up and self-tested in cgh_comm_init)
+    unsigned   epoch = 0;            // solves started so far (part of the tags of halo_ll.h)
 } g_rccl;
 
 int load_rccl()
@@ -176,15 +190,6 @@ inline int grid_for(int64_t work) { return cgh_stream_grid((work + 255) / 256, 8
 
 } // namespace
 
-// one neighbour's transfer as the peer-to-peer halo kernels see it
-struct halo_xfer {
-    double       *dst;     // push: the neighbour's deposit region for me (slot 0), as mapped here; pull: p + n_loc + recv_off
-    const double *src;     // pull: my deposit region for this neighbour (slot 0); push: unused
-    uint64_t     *flag;    // push: the neighbour's flag word for me; pull: my flag word for this neighbour
-    const int    *idx;     // push: rows to send, NULL when they are contiguous from `start`
-    int64_t       start, cnt;
-};
-
 // ------------------------------------------------------------------------------------------ per-rank state
 struct cgh_dist_nb {
     int      rank = -1;
@@ -214,13 +219,17 @@ struct cgh_dist {
     // group driver only
     double **d_locals = nullptr, **d_outs = nullptr;
     // peer-to-peer halo (optional, see "peer-to-peer halo" below): the neighbours deposit their boundary entries here
-    char    *hbuf = nullptr;                       // fine-grained, IPC-shared: [flags][per neighbour: 2 slots x recv_cnt doubles]
-    std::vector<size_t> h_off;                     // per neighbour: byte offset of its region in hbuf
+    char    *hbuf = nullptr;                       // fine-grained, IPC-shared: 2 slots x n_halo entries x 2 tagged words
     std::vector<void *> h_opened;                  // per neighbour: its hbuf as mapped here (hipIpcOpenMemHandle)
-    struct halo_xfer *d_push = nullptr, *d_pull = nullptr;   // device: one descriptor per neighbour
+    std::vector<halo_xfer> h_push;                 // per neighbour: where my boundary entries go
+    halo_xfer *d_push = nullptr;                   // the same on the device (stand-alone push kernel)
     int     *d_herr = nullptr;                     // device: 1 after a timed-out wait
     bool     halo_p2p = false;
-    unsigned hseq = 0;                             // halo exchanges so far
+    bool     fused_push = false;                   // dist_update_xp pushes (all send ranges contiguous, at most CGH_PUSH_MAX)
+    bool     loopback = false;                     // timing harness: every neighbour is this rank itself (cgh_dist_loopback)
+    unsigned epoch = 0;                            // number of this solve (same on every rank): part of every tag
+    int      pushed_iter = 0;                      // the exchange dist_update_xp has already pushed
+    bool     ll_spmv = false;                      // the boundary SpMV reads the deposit itself (vector path)
 };
 
 namespace {
@@ -260,6 +269,13 @@ int alloc_solver_state(cgh_dist *d, int capacity)
     d->gs = (double *)cgh_alloc(sizeof(double) * 8);
     d->done = (int *)cgh_alloc(sizeof(int) * 4);
     d->vgrid = cgh_stream_grid((d->n_loc + 2 * CGH_BLOCK - 1) / (2 * CGH_BLOCK), 8);
+    // Every workgroup of the two vector kernels waits for the peers' reduction messages.  Ranks on GPUs of their own
+    // never notice; ranks SHARING one GPU (the test harness) must leave room for each other's workgroups, or the
+    // waiting ones keep out the one that would send: CGH_DIST_GRID_MAX caps the grid for that case.
+    if (const char *env = getenv("CGH_DIST_GRID_MAX")) {
+        const int cap = atoi(env);
+        if (cap >= 1 && d->vgrid > cap) d->vgrid = cap;
+    }
     if (!d->p || !d->r || !d->Ap || !d->partA || !d->partB || !d->hist || !d->gs_local || !d->gs || !d->done) return CGH_ENOMEM;
     if (!d->ev_p) {
         CGH_HIP(hipEventCreateWithFlags(&d->ev_p, hipEventDisableTiming));
@@ -320,85 +336,41 @@ int finish_neighbours(cgh_dist *d)
 
 
 // ------------------------------------------------------------------------------------------ peer-to-peer halo
-// The same exchange without a library: rank g stores its boundary entries of p straight into a deposit buffer of the
-// neighbour (fine-grained device memory shared through hipIpc), fences, and raises the neighbour's flag word to the
-// sequence number of the exchange; the neighbour waits for the flag and copies the deposit into the halo tail of its
-// own p with ordinary local stores (so its SpMV reads coherent, cacheable memory).  Two deposit slots alternate: a rank
-// cannot start exchange k+2 before every neighbour has consumed exchange k (it needs their reduction messages of
-// iteration k+1, which they send after their SpMV of k+1).  Four workgroups per neighbour on either side, each with its
-// own quarter of the entries and its own flag word.
-constexpr int    HALO_SEG = 4;                    // workgroups (and flag words) per neighbour: each moves a quarter
-constexpr size_t HALO_FLAG_BYTES = 1024;          // 16 neighbours x 4 flag words + padding
+// The same exchange without a library and without a launch of its own.  Every rank owns a deposit buffer (fine-grained
+// device memory shared through hipIpc): two slots, each an image of the halo tail of p with every entry as two tagged
+// 64-bit words (halo_ll.h).  The kernel that writes p (dist_update_xp) also stores the rows a neighbour needs into that
+// neighbour's deposit, tagged with the NEXT iteration's exchange; the boundary-row SpMV of that iteration reads its halo
+// columns straight from its own deposit and waits, per entry, only if the tag is not there yet.  Two slots alternate: a
+// rank cannot push exchange k+2 before every neighbour has consumed exchange k (it needs their reduction messages of
+// iteration k+1, which they send after their SpMV of k+1).  Tags count (solve, iteration), so ranks stay in step
+// whatever they queue after convergence.
 constexpr int    HALO_MAX_NB = 16;
 constexpr size_t HALO_DESC_BYTES = 512;
 struct halo_desc {                                // what a rank tells the others about its deposit buffer
     char    handle[64];
     int32_t rank, n;
+    int64_t n_halo;
     struct {
-        int32_t src, flag_idx;
-        int64_t off, cnt;
+        int32_t src, pad;
+        int64_t recv_off, cnt;
     } e[HALO_MAX_NB];
 };
 static_assert(sizeof(halo_desc) <= HALO_DESC_BYTES, "descriptor size");
-
-__global__ __launch_bounds__(1024) void halo_push(const halo_xfer *__restrict__ xf, const double *__restrict__ p, unsigned seq)
-{
-    const halo_xfer a = xf[blockIdx.x / HALO_SEG];
-    const int       seg = blockIdx.x % HALO_SEG;
-    const int64_t   per = (a.cnt + HALO_SEG - 1) / HALO_SEG, k0 = seg * per, k1 = k0 + per < a.cnt ? k0 + per : a.cnt;
-    double         *dst = a.dst + (size_t)(seq & 1u) * (size_t)a.cnt;
-    for (int64_t k = k0 + threadIdx.x; k < k1; k += 1024) dst[k] = p[a.idx ? (int64_t)a.idx[k] : a.start + k];
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __threadfence_system();  // this segment's deposit before its flag
-        __hip_atomic_store(a.flag + seg, (uint64_t)seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-}
-
-__global__ __launch_bounds__(1024) void halo_pull(const halo_xfer *__restrict__ xf, unsigned seq, int *err)
-{
-    const halo_xfer a = xf[blockIdx.x / HALO_SEG];
-    const int       seg = blockIdx.x % HALO_SEG;
-    const int64_t   per = (a.cnt + HALO_SEG - 1) / HALO_SEG, k0 = seg * per, k1 = k0 + per < a.cnt ? k0 + per : a.cnt;
-    __shared__ int  ok;
-    if (threadIdx.x == 0) {
-        ok = 1;
-        if (*err != 0) {
-            ok = 0;  // an earlier wait timed out: never wait again
-        } else {
-            const long long t0 = wall_clock64();
-            // (the flag only grows; a neighbour cannot be more than one exchange ahead, and that one uses the other slot)
-            while (__hip_atomic_load(a.flag + seg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < (uint64_t)seq) {
-                if (wall_clock64() - t0 > 1000000000ll) {  // 10 s
-                    atomicExch(err, 1);
-                    ok = 0;
-                    break;
-                }
-                __builtin_amdgcn_s_sleep(2);
-            }
-        }
-    }
-    __syncthreads();
-    if (!ok) return;
-    __threadfence_system();
-    const uint64_t *src = reinterpret_cast<const uint64_t *>(a.src + (size_t)(seq & 1u) * (size_t)a.cnt);
-    for (int64_t k = k0 + threadIdx.x; k < k1; k += 1024)  // loads that bypass every cache: the words were written by a peer
-        a.dst[k] = __longlong_as_double((long long)__hip_atomic_load(src + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
-}
 
 void halo_release(cgh_dist *d)
 {
     for (void *p : d->h_opened)
         if (p) (void)hipIpcCloseMemHandle(p);
     d->h_opened.clear();
+    d->h_push.clear();
     cgh_free(d->d_push);
-    cgh_free(d->d_pull);
     cgh_free(d->d_herr);
-    d->d_push = d->d_pull = nullptr;
+    d->d_push = nullptr;
     d->d_herr = nullptr;
     if (d->hbuf) (void)hipFree(d->hbuf);
     d->hbuf = nullptr;
     d->halo_p2p = false;
+    d->fused_push = false;
 }
 
 int halo_descriptor(cgh_dist *d, char *out)
@@ -408,19 +380,14 @@ int halo_descriptor(cgh_dist *d, char *out)
         return CGH_EINVAL;
     }
     if (!d->hbuf) {
-        size_t bytes = HALO_FLAG_BYTES;
-        d->h_off.clear();
-        for (const cgh_dist_nb &nb : d->nbs) {
-            d->h_off.push_back(bytes);
-            bytes += ((size_t)(2 * nb.recv_cnt) * sizeof(double) + 255) & ~(size_t)255;
-        }
-        void *p = nullptr;
+        const size_t bytes = (size_t)(d->n_halo > 0 ? d->n_halo : 1) * 2 * 2 * sizeof(uint64_t);  // 2 slots x 2 words per entry
+        void        *p = nullptr;
         if (hipExtMallocWithFlags(&p, bytes, hipDeviceMallocFinegrained) != hipSuccess) {
             (void)hipGetLastError();
             CGH_HIP(hipMalloc(&p, bytes));
         }
         d->hbuf = (char *)p;
-        CGH_HIP(hipMemset(d->hbuf, 0, bytes));
+        CGH_HIP(hipMemset(d->hbuf, 0, bytes));  // tag 0 = nothing deposited yet
         CGH_HIP(hipDeviceSynchronize());
     }
     halo_desc h;
@@ -430,10 +397,10 @@ int halo_descriptor(cgh_dist *d, char *out)
     memcpy(h.handle, &ih, 64);
     h.rank = d->rank;
     h.n = (int32_t)d->nbs.size();
+    h.n_halo = d->n_halo;
     for (size_t i = 0; i < d->nbs.size(); ++i) {
         h.e[i].src = d->nbs[i].rank;
-        h.e[i].flag_idx = (int32_t)i;
-        h.e[i].off = (int64_t)d->h_off[i];
+        h.e[i].recv_off = d->nbs[i].recv_off;
         h.e[i].cnt = d->nbs[i].recv_cnt;
     }
     memset(out, 0, HALO_DESC_BYTES);
@@ -446,8 +413,9 @@ int halo_connect(cgh_dist *d, const char *all)
 {
     if (!d->hbuf) return CGH_EINVAL;
     const size_t nnb = d->nbs.size();
-    std::vector<halo_xfer> push(nnb ? nnb : 1), pull(nnb ? nnb : 1);
+    d->h_push.assign(nnb, halo_xfer{nullptr, nullptr, 0, 0, 0});
     d->h_opened.assign(nnb, nullptr);
+    bool contiguous = true;
     for (size_t i = 0; i < nnb; ++i) {
         const cgh_dist_nb &nb = d->nbs[i];
         halo_desc          h;
@@ -455,6 +423,7 @@ int halo_connect(cgh_dist *d, const char *all)
         int at = -1;
         for (int k = 0; k < h.n && k < HALO_MAX_NB; ++k)
             if (h.e[k].src == d->rank) at = k;
+        if (d->loopback) at = (int)(nnb - 1 - i);  // what leaves through the lower face comes back through the upper one
         if (h.rank != nb.rank || at < 0 || h.e[at].cnt != nb.send_cnt) {
             cgh_set_error("peer-to-peer halo: rank %d does not expect %lld entries from rank %d", nb.rank, (long long)nb.send_cnt, d->rank);
             return CGH_ECOMM;
@@ -473,47 +442,44 @@ int halo_connect(cgh_dist *d, const char *all)
             }
             d->h_opened[i] = base;
         }
-        push[i].dst = reinterpret_cast<double *>((char *)base + h.e[at].off);
-        push[i].src = nullptr;
-        push[i].flag = reinterpret_cast<uint64_t *>(base) + (size_t)h.e[at].flag_idx * HALO_SEG;
-        push[i].idx = nb.contig_start >= 0 ? nullptr : nb.d_send_idx;
-        push[i].start = nb.contig_start >= 0 ? nb.contig_start : 0;
-        push[i].cnt = nb.send_cnt;
-        pull[i].dst = nullptr;  // p is allocated per solve: filled in by halo_bind()
-        pull[i].src = reinterpret_cast<const double *>(d->hbuf + d->h_off[i]);
-        pull[i].flag = reinterpret_cast<uint64_t *>(d->hbuf) + i * HALO_SEG;
-        pull[i].idx = nullptr;
-        pull[i].start = nb.recv_off;
-        pull[i].cnt = nb.recv_cnt;
+        halo_xfer &x = d->h_push[i];
+        x.dst = reinterpret_cast<uint64_t *>(base) + 2 * (size_t)h.e[at].recv_off;
+        x.idx = nb.contig_start >= 0 ? nullptr : nb.d_send_idx;
+        x.start = nb.contig_start >= 0 ? nb.contig_start : 0;
+        x.cnt = nb.send_cnt;
+        x.slot_words = 2 * h.n_halo;
+        contiguous = contiguous && nb.contig_start >= 0;
     }
     d->d_push = (halo_xfer *)cgh_alloc(sizeof(halo_xfer) * (nnb ? nnb : 1));
-    d->d_pull = (halo_xfer *)cgh_alloc(sizeof(halo_xfer) * (nnb ? nnb : 1));
     d->d_herr = (int *)cgh_alloc(sizeof(int));
-    if (!d->d_push || !d->d_pull || !d->d_herr) return CGH_ENOMEM;
-    int rc = cgh_h2d(d->d_push, push.data(), sizeof(halo_xfer) * (nnb ? nnb : 1));
-    if (rc == CGH_OK) rc = cgh_h2d(d->d_pull, pull.data(), sizeof(halo_xfer) * (nnb ? nnb : 1));
+    if (!d->d_push || !d->d_herr) return CGH_ENOMEM;
+    int rc = nnb ? cgh_h2d(d->d_push, d->h_push.data(), sizeof(halo_xfer) * nnb) : CGH_OK;
     if (rc == CGH_OK) rc = cgh_memset(d->d_herr, 0, sizeof(int));
     if (rc) return rc;
-    d->hseq = 0;
+    const char *env = getenv("CGH_FUSED_PUSH");
+    d->fused_push = contiguous && nnb <= (size_t)CGH_PUSH_MAX && !(env && atoi(env) == 0);
     d->halo_p2p = true;
     return CGH_OK;
 }
 
-// the pull descriptors point into this solve's p
-__global__ void halo_bind_kernel(halo_xfer *pull, int n, double *halo_base)
+// the stand-alone push of exchange `iter` (first exchange of a solve; send lists that dist_update_xp cannot serve)
+void halo_push_launch(cgh_dist *d, int iter, hipStream_t s)
 {
-    if ((int)threadIdx.x < n) pull[threadIdx.x].dst = halo_base + pull[threadIdx.x].start;
+    int64_t most = 1;
+    for (const cgh_dist_nb &nb : d->nbs) most = nb.send_cnt > most ? nb.send_cnt : most;
+    const int per = (int)((most + 511) / 512 < 64 ? (most + 511) / 512 : 64);
+    hipLaunchKernelGGL(halo_push_ll, dim3(per, (unsigned)d->nbs.size()), dim3(256), 0, s, (const halo_xfer *)d->d_push, (const double *)d->p,
+                       cgh_ll_tag(d->epoch, (unsigned)iter), iter & 1, (const int *)d->done);
 }
 
-int exchange_p2p(cgh_dist *d, hipStream_t c)
+cgh_ll_halo halo_view(const cgh_dist *d, int iter)
 {
-    if (d->nbs.empty()) return CGH_OK;
-    const unsigned seq = ++d->hseq;
-    const unsigned nnb = (unsigned)d->nbs.size() * HALO_SEG;
-    hipLaunchKernelGGL(halo_push, dim3(nnb), dim3(1024), 0, c, (const halo_xfer *)d->d_push, (const double *)d->p, seq);
-    hipLaunchKernelGGL(halo_pull, dim3(nnb), dim3(1024), 0, c, (const halo_xfer *)d->d_pull, seq, d->d_herr);
-    CGH_HIP(hipGetLastError());
-    return CGH_OK;
+    cgh_ll_halo h;
+    h.dep = reinterpret_cast<const uint64_t *>(d->hbuf) + (size_t)(iter & 1) * 2 * (size_t)d->n_halo;
+    h.nl = d->n_loc;
+    h.tag = cgh_ll_tag(d->epoch, (unsigned)iter);
+    h.err = d->d_herr;
+    return h;
 }
 
 } // namespace
@@ -707,6 +673,31 @@ int cgh_dist_halo_connect(cgh_dist *d, const char *descriptors)
 }
 
 int cgh_dist_halo_is_p2p(const cgh_dist *d) { return d && d->halo_p2p ? 1 : 0; }
+
+// Timing harness for ONE GPU: turn an inner slab (created as rank r of N while the communicator has one rank) into a
+// one-rank problem whose two neighbours are this rank itself -- what it pushes through its lower face arrives in its
+// own upper halo and vice versa, i.e. the slab's operator closed periodically in z (still symmetric and diagonally
+// dominant).  Kernels, bytes, flags and waits per iteration are those of an inner rank of the N-GPU run; only the
+// xGMI hop is missing.
+int cgh_dist_loopback(cgh_dist *d)
+{
+    CGH_REQUIRE_READY(CGH_ENODEV);
+    if (!d || d->nbs.size() != 2 || !g_rccl.p2p || g_rccl.nranks != 1 || d->nbs[0].send_cnt != d->nbs[1].recv_cnt ||
+        d->nbs[1].send_cnt != d->nbs[0].recv_cnt) {
+        cgh_set_error("cgh_dist_loopback: needs an inner slab (two neighbours) and a one-rank peer-to-peer communicator");
+        return CGH_EINVAL;
+    }
+    halo_release(d);
+    d->nranks = 1;
+    d->rank = 0;
+    for (cgh_dist_nb &nb : d->nbs) nb.rank = 0;
+    d->loopback = true;
+    char desc[HALO_DESC_BYTES];
+    int  rc = halo_descriptor(d, desc);
+    if (rc == CGH_OK) rc = halo_connect(d, desc);
+    if (rc != CGH_OK) d->halo_p2p = false;
+    return rc;
+}
 
 // Use (1) or bypass (0) the peer-to-peer scalar all-reduce for the following solves; it can only be switched on if
 // cgh_comm_init connected it.  Every rank must make the same choice.  Returns the state now in force.
@@ -912,8 +903,13 @@ int cgh_dist_start(cgh_dist *d, const double *d_b, double *d_x, double tol, int 
     CGH_HIP(hipMemsetAsync(d->done, 0, sizeof(int) * 4, s));
     CGH_HIP(hipMemsetAsync(d_x, 0, sizeof(double) * (size_t)nl, s));
     CGH_HIP(hipMemsetAsync(d->p, 0, sizeof(double) * (size_t)(nl + d->n_halo), s));  // x0 = 0, halo of x0 = 0
-    if (d->halo_p2p && !d->nbs.empty())
-        hipLaunchKernelGGL(halo_bind_kernel, dim3(1), dim3(64), 0, s, d->d_pull, (int)d->nbs.size(), d->p + nl);
+    d->epoch = ++g_rccl.epoch;   // every rank starts its solves in the same order: the same number everywhere
+    d->pushed_iter = 0;
+    d->ll_spmv = cgh_spmv_ell_halo_capable(&d->mat, d->p, d->Ap, 0, d->int_begin, d->int_end, nl);
+    {
+        const char *env = getenv("CGH_DIST_LL_SPMV");
+        if (env && atoi(env) == 0) d->ll_spmv = false;
+    }
     int cnt = 0;
     rc = spmv_ranges(d, true, true, false, &cnt, s, nullptr);  // Ap = A*0, as the reference computes it (cg.c:441)
     if (rc) return rc;
@@ -940,14 +936,20 @@ int cgh_dist_iterate(cgh_dist *d, int count, int time_kernels)
     }
     hipStream_t   s = g_cgh.stream, c = g_cgh.comm_stream;
     const int64_t nl = d->n_loc;
+    static const bool one_spmv = getenv("CGH_DIST_ONE_SPMV") && atoi(getenv("CGH_DIST_ONE_SPMV")) != 0;
     for (int k = 0; k < count; ++k) {
-        const int iter = ++d->queued;
-        // halo exchange of p on the communication stream, behind the kernel that last wrote p
-        CGH_HIP(hipEventRecord(d->ev_p, s));
-        CGH_HIP(hipStreamWaitEvent(c, d->ev_p, 0));
-        int rc = (g_rccl.p2p && d->halo_p2p) ? exchange_p2p(d, c) : exchange_rccl(d, c);
-        if (rc) return rc;
-        CGH_HIP(hipEventRecord(d->ev_halo, c));
+        const int  iter = ++d->queued;
+        const bool halo = !d->nbs.empty(), direct = halo && g_rccl.p2p && d->halo_p2p, folded = g_rccl.p2p;
+        int        rc;
+        if (halo && !direct) {
+            // RCCL halo exchange of p on the communication stream, behind the kernel that last wrote p
+            CGH_HIP(hipEventRecord(d->ev_p, s));
+            CGH_HIP(hipStreamWaitEvent(c, d->ev_p, 0));
+            rc = exchange_rccl(d, c);
+            if (rc) return rc;
+            CGH_HIP(hipEventRecord(d->ev_halo, c));
+        }
+        if (direct && d->pushed_iter != iter) halo_push_launch(d, iter, s);  // (else dist_update_xp of iter-1 pushed it)
         if (time_kernels) {
             hipEvent_t a, b;
             CGH_HIP(hipEventCreate(&a));
@@ -957,30 +959,71 @@ int cgh_dist_iterate(cgh_dist *d, int count, int time_kernels)
             CGH_HIP(hipEventRecord(a, s));
         }
         int cnt = 0;
-        rc = spmv_ranges(d, true, false, true, &cnt, s, d->done);   // interior rows: overlap the exchange
-        if (rc) return rc;
-        CGH_HIP(hipStreamWaitEvent(s, d->ev_halo, 0));
-        rc = spmv_ranges(d, false, true, true, &cnt, s, d->done);   // boundary rows
-        if (rc) return rc;
-        if (time_kernels) CGH_HIP(hipEventRecord(d->kev.back(), s));
-        if (g_rccl.p2p) {  // one kernel: local sum, peer stores, wait, sum over ranks
-            rc = cgh_p2p_launch(1, d->partA, cnt, d->gs, s);
+        if (direct) {
+            const cgh_ll_halo hl = halo_view(d, iter);
+            const int64_t     a = d->int_begin, b = d->int_end;
+            int               g = 0;
+            if (d->ll_spmv && one_spmv) {  // experiment: one launch over all rows
+                rc = cgh_launch_spmv_ell_halo(&d->mat, d->p, d->Ap, d->partA, &g, d->done, s, 0, nl, 0, 0, &hl);
+                if (rc) return rc;
+                cnt = g;
+            } else {
+                rc = spmv_ranges(d, true, false, true, &cnt, s, d->done);  // interior rows: the neighbours' pushes arrive meanwhile
+                if (rc) return rc;
+                if (d->ll_spmv) {
+                    rc = cgh_launch_spmv_ell_halo(&d->mat, d->p, d->Ap, d->partA + cnt, &g, d->done, s, 0, a, b, nl, &hl);
+                    if (rc) return rc;
+                    cnt += g;
+                } else {  // this matrix' SpMV cannot read the deposit: unpack it into the halo tail of p first
+                    const int64_t blocks = (d->n_halo + 255) / 256;
+                    hipLaunchKernelGGL(halo_pull_ll, dim3((unsigned)(blocks < 256 ? blocks : 256)), dim3(256), 0, s, hl, d->n_halo, d->p + nl,
+                                       (const int *)d->done);
+                    rc = spmv_ranges(d, false, true, true, &cnt, s, d->done);
+                    if (rc) return rc;
+                }
+            }
+        } else {
+            rc = spmv_ranges(d, true, false, true, &cnt, s, d->done);   // interior rows: overlap the exchange
             if (rc) return rc;
+            if (halo) CGH_HIP(hipStreamWaitEvent(s, d->ev_halo, 0));
+            rc = spmv_ranges(d, false, true, true, &cnt, s, d->done);   // boundary rows
+            if (rc) return rc;
+        }
+        if (time_kernels) CGH_HIP(hipEventRecord(d->kev.back(), s));
+        if (folded) {  // the all-reduces happen inside the kernels that consume them
+            cgh_link L;
+            rc = cgh_p2p_link(&L);
+            if (rc) return rc;
+            L.self = d->loopback ? 1 : 0;
+            L.tag = cgh_ll_tag(d->epoch, 2u * (unsigned)iter);
+            hipLaunchKernelGGL(dist_update_r, dim3(d->vgrid), dim3(CGH_BLOCK), 0, s, nl, d->r, (const double *)d->Ap, (const double *)d->partA,
+                               cnt, d->partB, d->hist, iter, (const int *)d->done, L);
+            L.tag = cgh_ll_tag(d->epoch, 2u * (unsigned)iter + 1u);
+            cgh_pushes P;
+            memset(&P, 0, sizeof P);
+            if (direct && d->fused_push) {  // exchange iter+1 leaves with the p it is made of
+                P.n = (int)d->h_push.size();
+                P.tag = cgh_ll_tag(d->epoch, (unsigned)(iter + 1));
+                for (int j = 0; j < P.n; ++j) {
+                    P.start[j] = d->h_push[j].start;
+                    P.cnt[j] = d->h_push[j].cnt;
+                    P.dst[j] = d->h_push[j].dst + (size_t)((iter + 1) & 1) * (size_t)d->h_push[j].slot_words;
+                }
+                d->pushed_iter = iter + 1;
+            }
+            hipLaunchKernelGGL(dist_update_xp, dim3(d->vgrid), dim3(CGH_BLOCK), 0, s, nl, d->x, (const double *)d->r, d->p,
+                               (const double *)d->partB, d->vgrid, d->hist, iter, d->tol, d->done, L, P);
         } else {
             hipLaunchKernelGGL(reduce_local<1>, dim3(1), dim3(CGH_BLOCK), 0, s, (const double *)d->partA, cnt, d->gs_local);
             CGH_NCCL(g_rccl.AllReduce(d->gs_local, d->gs, 1, ncclDouble, ncclSum, g_rccl.comm, s));
-        }
-        hipLaunchKernelGGL((cg_update_r<2, 3>), dim3(d->vgrid), dim3(CGH_BLOCK), 0, s, nl, d->r, (const double *)d->Ap,
-                           (const double *)nullptr, 0, d->partB, d->hist, iter, (const int *)d->done, 0, (const double *)d->gs);
-        if (g_rccl.p2p) {
-            rc = cgh_p2p_launch(2, d->partB, d->vgrid, d->gs + 1, s);
-            if (rc) return rc;
-        } else {
+            hipLaunchKernelGGL((cg_update_r<2, 3>), dim3(d->vgrid), dim3(CGH_BLOCK), 0, s, nl, d->r, (const double *)d->Ap,
+                               (const double *)nullptr, 0, d->partB, d->hist, iter, (const int *)d->done, 0, (const double *)d->gs,
+                               (double *)nullptr, (int64_t)0);
             hipLaunchKernelGGL(reduce_local<2>, dim3(2), dim3(CGH_BLOCK), 0, s, (const double *)d->partB, d->vgrid, d->gs_local + 1);
             CGH_NCCL(g_rccl.AllReduce(d->gs_local + 1, d->gs + 1, 2, ncclDouble, ncclSum, g_rccl.comm, s));
+            hipLaunchKernelGGL((cg_update_xp<2, 3>), dim3(d->vgrid), dim3(CGH_BLOCK), 0, s, nl, d->x, (const double *)d->r, d->p,
+                               (const double *)nullptr, 0, d->hist, iter, d->tol, d->done, 0, (const double *)d->gs);
         }
-        hipLaunchKernelGGL((cg_update_xp<2, 3>), dim3(d->vgrid), dim3(CGH_BLOCK), 0, s, nl, d->x, (const double *)d->r, d->p,
-                           (const double *)nullptr, 0, d->hist, iter, d->tol, d->done, 0, (const double *)d->gs);
         CGH_HIP(hipGetLastError());
     }
     return CGH_OK;

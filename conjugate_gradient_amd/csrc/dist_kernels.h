@@ -1,0 +1,154 @@
+// dist_kernels.h -- the two vector kernels of the multi-GPU iteration with their communication folded in, and the
+// stand-alone halo kernels for the cases the fused path does not cover.  New module, no reference counterpart
+// (SURVEY.md 8e); the arithmetic on r, x, p is that of cg_update_r / cg_update_xp (cg_kernels.h), i.e. reference
+// src/cg.c:463-489.
+//
+//   dist_update_r    prologue: p.Ap of this rank from the SpMV's partials, all-reduced over the ranks through the
+//                    mailboxes (link_allreduce); then r -= alpha Ap and the partials of r.r, |r|_1
+//   dist_update_xp   prologue: r.r and |r|_1 all-reduced the same way; x += alpha p, convergence test, p = r + beta p;
+//                    rows of p inside a neighbour's send range also go, tagged, into that neighbour's deposit buffer
+//                    (the halo exchange of the NEXT iteration costs no launch and starts as early as it can)
+//   halo_push_ll     the same push as a kernel of its own: the first exchange of a solve (p = r0 comes from cg_init_rp)
+//                    and send lists that are not contiguous
+//   halo_pull_ll     deposit slot -> halo tail of p, for SpMV paths that cannot read the deposit themselves
+// Per iteration an inner rank launches: interior SpMV, boundary SpMV (reads the deposit), dist_update_r,
+// dist_update_xp -- four kernels on one stream, no events, no library call.
+#pragma once
+#include "cg_kernels.h"
+#include "halo_ll.h"
+
+namespace {
+
+__global__ __launch_bounds__(CGH_BLOCK) void dist_update_r(int64_t n, double *__restrict__ r, const double *__restrict__ Ap,
+                                                          const double *__restrict__ pAp_partials, int pAp_count,
+                                                          double *__restrict__ out_partials, double *hist, int iter,
+                                                          const int *__restrict__ done, cgh_link L)
+{
+    __shared__ double lds[4];
+    __shared__ double ex[2 * CGH_LINK_MAX_RANKS];
+    if (*done != 0) return;  // frozen on every rank alike (the flag derives from all-reduced scalars): nobody exchanges
+    double mine[1] = {block_sum_partials(pAp_partials, pAp_count, 1, lds)}, pAp[1];
+    link_allreduce<1>(L, mine, pAp, ex);
+    const double alpha = hist[(size_t)(iter - 1) * HIST + 1] / pAp[0];
+    if (blockIdx.x == 0 && threadIdx.x == 0) hist[(size_t)iter * HIST + 2] = alpha;
+    const double  nalpha = -alpha;
+    double        rr = 0.0, l1 = 0.0;
+    const int64_t pairs = n >> 1;
+    const int64_t chunks = (pairs + CGH_BLOCK - 1) / CGH_BLOCK;
+    for (int64_t cc = blockIdx.x; cc < chunks; cc += gridDim.x) {
+        const int64_t k = cc * CGH_BLOCK + threadIdx.x;
+        if (k >= pairs) continue;
+        const double2 rv = ld2<3>(r, k), av = ld2<3>(Ap, k);
+        const double2 rn = make_double2(madd_rn(rv.x, nalpha, av.x), madd_rn(rv.y, nalpha, av.y));  // vec.c:88-94, cg.c:469
+        st2<false>(r, k, rn.x, rn.y);
+        rr += rn.x * rn.x + rn.y * rn.y;
+        l1 += fabs(rn.x) + fabs(rn.y);
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+        const double rn = madd_rn(r[n - 1], nalpha, Ap[n - 1]);
+        r[n - 1] = rn;
+        rr += rn * rn;
+        l1 += fabs(rn);
+    }
+    const double trr = block_sum_256(rr, lds);
+    const double tl1 = block_sum_256(l1, lds);
+    if (threadIdx.x == 0) {
+        out_partials[2 * blockIdx.x] = trr;
+        out_partials[2 * blockIdx.x + 1] = tl1;
+    }
+}
+
+__device__ __forceinline__ void push_row(const cgh_pushes &P, int64_t row, double v)
+{
+    for (int j = 0; j < P.n; ++j) {
+        const int64_t k = row - P.start[j];
+        if (k >= 0 && k < P.cnt[j]) ll_store(P.dst[j] + 2 * k, v, P.tag);
+    }
+}
+
+__global__ __launch_bounds__(CGH_BLOCK) void dist_update_xp(int64_t n, double *__restrict__ x, const double *__restrict__ r,
+                                                           double *__restrict__ p, const double *__restrict__ partials, int count,
+                                                           double *hist, int iter, double tol, int *done, cgh_link L, cgh_pushes P)
+{
+    __shared__ double lds[4];
+    __shared__ double ex[2 * CGH_LINK_MAX_RANKS];
+    // The flag may name THIS iteration: workgroup 0 of this very launch publishes the verdict (below) while later
+    // workgroups are still starting -- they go on and reach the same verdict (the peers' messages stay in the mailbox).
+    const int frozen_at = *done;
+    if (frozen_at != 0 && frozen_at != iter) return;
+    double mine[2], tot[2];
+    mine[0] = block_sum_partials(partials, count, 2, lds);
+    mine[1] = block_sum_partials(partials + 1, count, 2, lds);
+    link_allreduce<2>(L, mine, tot, ex);
+    const double alpha = hist[(size_t)iter * HIST + 2];
+    const double res = tot[1] / 2.0;  // norm_factor = 2.0, cg.c:427,475
+    const bool   conv = res < tol;
+    const double beta = tot[0] / hist[(size_t)(iter - 1) * HIST + 1];
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        hist[(size_t)iter * HIST + 0] = res;
+        hist[(size_t)iter * HIST + 1] = tot[0];
+        hist[(size_t)iter * HIST + 3] = conv ? NAN : beta;
+        done[2] = iter;
+    }
+    const int64_t pairs = n >> 1;
+    const int64_t chunks = (pairs + CGH_BLOCK - 1) / CGH_BLOCK;
+    if (conv) {
+        // the reference updates x, then returns before touching p (cg.c:467-485); every workgroup (on every rank) reaches
+        // the same verdict from the same scalars, workgroup 0 publishes it for the launches behind this one
+        for (int64_t cc = blockIdx.x; cc < chunks; cc += gridDim.x) {
+            const int64_t k = cc * CGH_BLOCK + threadIdx.x;
+            if (k >= pairs) continue;
+            const double2 xv = ld2<3>(x, k), pv = ld2<3>(p, k);
+            st2<true>(x, k, madd_rn(xv.x, alpha, pv.x), madd_rn(xv.y, alpha, pv.y));
+        }
+        if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) x[n - 1] = madd_rn(x[n - 1], alpha, p[n - 1]);
+        if (blockIdx.x == 0 && threadIdx.x == 0) *done = iter;
+        return;
+    }
+    for (int64_t cc = blockIdx.x; cc < chunks; cc += gridDim.x) {
+        const int64_t k = cc * CGH_BLOCK + threadIdx.x;
+        if (k >= pairs) continue;
+        const double2 xv = ld2<3>(x, k), rv = ld2<3>(r, k), pv = ld2<3>(p, k);
+        // reference vec_axpy: out = a + alpha*b (vec.c:88-94): x += alpha p (cg.c:467), p = r + beta p (cg.c:489)
+        st2<true>(x, k, madd_rn(xv.x, alpha, pv.x), madd_rn(xv.y, alpha, pv.y));
+        const double p0 = madd_rn(rv.x, beta, pv.x), p1 = madd_rn(rv.y, beta, pv.y);
+        st2<false>(p, k, p0, p1);
+        if (P.n > 0) {
+            push_row(P, 2 * k, p0);
+            push_row(P, 2 * k + 1, p1);
+        }
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+        x[n - 1] = madd_rn(x[n - 1], alpha, p[n - 1]);
+        const double pn = madd_rn(r[n - 1], beta, p[n - 1]);
+        p[n - 1] = pn;
+        push_row(P, n - 1, pn);
+    }
+}
+
+// one neighbour's transfer as the stand-alone halo kernels see it
+struct halo_xfer {
+    uint64_t  *dst;      // push: the neighbour's deposit (slot 0) at my region, as mapped here
+    const int *idx;      // push: rows to send, NULL when they are contiguous from `start`
+    int64_t    start, cnt, slot_words;   // slot_words: 64-bit words between the two slots of that deposit
+};
+
+// grid: (workgroups per neighbour, neighbours)
+__global__ __launch_bounds__(256) void halo_push_ll(const halo_xfer *__restrict__ xf, const double *__restrict__ p, unsigned tag,
+                                                   int slot, const int *__restrict__ done)
+{
+    if (done != nullptr && *done != 0) return;
+    const halo_xfer a = xf[blockIdx.y];
+    uint64_t       *dst = a.dst + (size_t)slot * (size_t)a.slot_words;
+    for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < a.cnt; k += (int64_t)gridDim.x * 256)
+        ll_store(dst + 2 * k, p[a.idx ? (int64_t)a.idx[k] : a.start + k], tag);
+}
+
+__global__ __launch_bounds__(256) void halo_pull_ll(cgh_ll_halo h, int64_t n_halo, double *__restrict__ halo_tail,
+                                                   const int *__restrict__ done)
+{
+    if (done != nullptr && *done != 0) return;
+    for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < n_halo; k += (int64_t)gridDim.x * 256) halo_tail[k] = ll_read(h, k);
+}
+
+} // namespace

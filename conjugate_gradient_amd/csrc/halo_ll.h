@@ -1,0 +1,118 @@
+// halo_ll.h -- what the kernels of the multi-GPU iteration share: tagged 64-bit words over peer-mapped memory.
+// New module, no reference counterpart.
+//
+// A double travels as TWO 64-bit words, each carrying 32 bits of data below the 32-bit tag of its exchange (the "LL"
+// encoding of NCCL's low-latency protocol): a word is valid exactly when its tag matches, so neither side needs a fence,
+// a flag or an atomic counter -- the writer stores with system scope (write-through), the reader polls the very words
+// it needs.  Tags are derived from (solve number, iteration, which exchange of the iteration), never from a host-side
+// launch count, so ranks may queue different numbers of frozen (post-convergence) iterations without losing step.
+//
+//   cgh_link      the two scalar all-reduces of an iteration, folded into the prologue of the kernel that consumes the
+//                 sum (link_allreduce): workgroup 0 stores this rank's value into every peer's mailbox, every workgroup
+//                 polls its own mailbox for the peers' values and adds the N values in rank order (same bits everywhere)
+//   cgh_ll_halo   the deposit buffer a boundary SpMV reads halo entries of p from (ll_read), written by the neighbours'
+//                 p-update kernels (ll_store)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+constexpr int CGH_LINK_MAX_RANKS = 16, CGH_LINK_SLOTS = 4, CGH_LINK_WORDS = 4;
+// mailbox: [region][slot][sender rank][word]; region 0 = exchanges numbered by a host counter (p2p.hip: start-up, tests),
+// region 1 = exchanges numbered by iteration (this header)
+constexpr size_t CGH_LINK_REGION_WORDS = (size_t)CGH_LINK_SLOTS * CGH_LINK_MAX_RANKS * CGH_LINK_WORDS;
+constexpr long long CGH_LL_TIMEOUT_TICKS = 1000000000ll;  // 10 s of the 100 MHz constant clock
+
+struct cgh_link {
+    uint64_t *const *peers;  // [nranks]: every rank's mailbox as mapped here
+    const uint64_t  *box;    // this rank's mailbox
+    int             *err;    // device word, 1 after a timed-out wait (then nobody waits again)
+    int              nranks, me;
+    int              self;   // 1: this rank's own value goes through its mailbox too (one-rank timing harness)
+    unsigned         tag;    // of this exchange; its slot is (tag & 3)
+};
+
+struct cgh_ll_halo {
+    const uint64_t *dep;     // this exchange's slot of my deposit buffer: 2 words per halo entry, in halo order
+    int64_t         nl;      // owned entries of p: column c >= nl is halo entry c - nl
+    unsigned        tag;
+    int            *err;
+};
+
+constexpr int CGH_PUSH_MAX = 4;
+struct cgh_pushes {          // contiguous send ranges of p, pushed by the kernel that writes p
+    int       n;
+    unsigned  tag;
+    int64_t   start[CGH_PUSH_MAX], cnt[CGH_PUSH_MAX];
+    uint64_t *dst[CGH_PUSH_MAX];   // the neighbour's deposit slot for this exchange, at my region, as mapped here
+};
+
+// tag of exchange `idx` of solve `epoch`: never 0 (the value of a fresh buffer), low 2 bits = idx & 3
+__host__ __device__ inline unsigned cgh_ll_tag(unsigned epoch, unsigned idx)
+{
+    return 0x80000000u | ((epoch & 0x7ffu) << 20) | (idx & 0xfffffu);
+}
+
+#ifdef __HIPCC__
+__device__ __forceinline__ void ll_store(uint64_t *dst, double v, unsigned tag)
+{
+    const uint64_t bits = (uint64_t)__double_as_longlong(v), t = (uint64_t)tag << 32;
+    __hip_atomic_store(dst, t | (bits & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(dst + 1, t | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// Wait for the two words at q to carry `tag`; NaN (and *err = 1) after 10 s, or at once if an earlier wait timed out.
+__device__ __forceinline__ double ll_wait(const uint64_t *q, unsigned tag, int *err)
+{
+    uint64_t lo = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    uint64_t hi = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if ((unsigned)(lo >> 32) != tag || (unsigned)(hi >> 32) != tag) {
+        if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return __builtin_nan("");
+        const long long t0 = wall_clock64();
+        while (true) {
+            __builtin_amdgcn_s_sleep(2);
+            lo = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            hi = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if ((unsigned)(lo >> 32) == tag && (unsigned)(hi >> 32) == tag) break;
+            if (wall_clock64() - t0 > CGH_LL_TIMEOUT_TICKS) {
+                atomicExch(err, 1);
+                return __builtin_nan("");
+            }
+        }
+    }
+    return __longlong_as_double((long long)((hi << 32) | (lo & 0xffffffffull)));
+}
+
+__device__ __forceinline__ double ll_read(const cgh_ll_halo &h, int64_t entry) { return ll_wait(h.dep + 2 * entry, h.tag, h.err); }
+
+// out[w] = sum over ranks (rank order) of mine[w], w < W <= 2.  Called by all 256 threads of every workgroup of the
+// launch with the same `mine`; `ex` holds 2*16 doubles of LDS.  Every thread returns the same bits on every rank.
+template <int W>
+__device__ __forceinline__ void link_allreduce(const cgh_link &L, const double *mine, double *out, double *ex)
+{
+    const int t = threadIdx.x;
+    if (L.nranks > 1 || L.self) {
+        const int    slot = (int)(L.tag & (CGH_LINK_SLOTS - 1));
+        const size_t base = CGH_LINK_REGION_WORDS + (size_t)slot * CGH_LINK_MAX_RANKS * CGH_LINK_WORDS;
+        if (t < L.nranks * W) {
+            const int peer = t / W, w = t % W;
+            if (peer == L.me && !L.self) {
+                ex[t] = mine[w];
+            } else {
+                if (blockIdx.x == 0) ll_store(L.peers[peer] + base + (size_t)L.me * CGH_LINK_WORDS + 2 * w, mine[w], L.tag);
+                ex[t] = ll_wait(L.box + base + (size_t)peer * CGH_LINK_WORDS + 2 * w, L.tag, L.err);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int w = 0; w < W; ++w) {
+            double s = 0.0;
+            for (int r = 0; r < L.nranks; ++r) s += ex[r * W + w];
+            out[w] = s;
+        }
+        __syncthreads();
+    } else {
+#pragma unroll
+        for (int w = 0; w < W; ++w) out[w] = 0.0 + mine[w];
+    }
+}
+#endif

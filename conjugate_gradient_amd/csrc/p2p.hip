@@ -19,11 +19,14 @@
 // min-reduce) whether to use this path; on any failure the RCCL all-reduces stay.  CGH_P2P=0 disables it.
 #include "cgh_internal.h"
 #include "device_utils.h"
+#include "halo_ll.h"
 
 namespace {
 
-constexpr int P2P_MAX_RANKS = 16, P2P_SLOTS = 4, P2P_WORDS = 4;
-constexpr size_t P2P_BOX_WORDS = (size_t)P2P_SLOTS * P2P_MAX_RANKS * P2P_WORDS;
+constexpr int P2P_MAX_RANKS = CGH_LINK_MAX_RANKS, P2P_SLOTS = CGH_LINK_SLOTS, P2P_WORDS = CGH_LINK_WORDS;
+// region 0: the exchanges of this file (numbered by g_p2p.seq); region 1: those folded into the kernels of the
+// iteration (halo_ll.h, numbered by solve and iteration)
+constexpr size_t P2P_BOX_WORDS = 2 * CGH_LINK_REGION_WORDS;
 
 struct p2p_state {
     bool      connected = false;
@@ -205,6 +208,20 @@ int cgh_p2p_allreduce_f64(double *h_vals, int count)
 }
 
 } // extern "C"
+
+// The mailboxes as the kernels of the iteration see them (dist.hip fills in tag and self).
+int cgh_p2p_link(cgh_link *L)
+{
+    if (!g_p2p.connected) return CGH_EINVAL;
+    L->peers = (uint64_t *const *)g_p2p.d_peers;
+    L->box = g_p2p.box;
+    L->err = g_p2p.d_err;
+    L->nranks = g_p2p.nranks;
+    L->me = g_p2p.rank;
+    L->self = 0;
+    L->tag = 0;
+    return CGH_OK;
+}
 
 // out[w] = sum over ranks of (sum of this rank's W-interleaved partials, `count` per scalar), w < W <= 2.
 int cgh_p2p_launch(int W, const double *partials, int count, double *out, hipStream_t s)

@@ -19,6 +19,7 @@
 
 #include "cgh_internal.h"
 #include "device_utils.h"
+#include "halo_ll.h"
 
 namespace {
 
@@ -59,14 +60,26 @@ __device__ __forceinline__ i2_t load_cols(const void *__restrict__ cols, const i
     }
 }
 
-template <int KT, int DOT, int VAR, int DICT = 0>
+// x[c] for a stored column id (pads, c < 0, read the row's own entry and are discarded by the caller).  HALO: ids from
+// hl.nl on are halo entries of a multi-GPU block, read from the deposit buffer the neighbours write into (halo_ll.h) --
+// the wait for a neighbour's push happens here, in the lanes that need the entry, and nowhere else.
+template <int HALO>
+__device__ __forceinline__ double gather_x(const double *__restrict__ x, int c, int64_t i0, const cgh_ll_halo &hl)
+{
+    if constexpr (HALO != 0) {
+        if ((int64_t)c >= hl.nl) return ll_read(hl, (int64_t)c - hl.nl);
+    }
+    return x[c >= 0 ? (int64_t)c : i0];
+}
+
+template <int KT, int DOT, int VAR, int DICT = 0, int HALO = 0>
 __global__ __launch_bounds__(CGH_BLOCK) void spmv_ell_r2(int64_t n, int Krt, const double *__restrict__ diag,
                                                         const double *__restrict__ vals, const void *__restrict__ cols,
                                                         const int *__restrict__ off_tab,
                                                         const double *__restrict__ x, double *__restrict__ y,
                                                         double *__restrict__ partials, const int *__restrict__ done,
                                                         int rev, int64_t row_begin, int64_t row_end, int64_t row_begin2,
-                                                        int64_t row_end2)
+                                                        int64_t row_end2, cgh_ll_halo hl)
 {
     __shared__ double lds[4];
     __shared__ int    tab[DICT ? 256 : 1];
@@ -135,8 +148,8 @@ __global__ __launch_bounds__(CGH_BLOCK) void spmv_ell_r2(int64_t n, int Krt, con
                     g0[s] = xi.x + (double)c[s].x;
                     g1[s] = xi.y + (double)c[s].y;
                 } else {
-                    g0[s] = x[c[s].x >= 0 ? (int64_t)c[s].x : i0];
-                    g1[s] = x[c[s].y >= 0 ? (int64_t)c[s].y : i0];
+                    g0[s] = gather_x<HALO>(x, c[s].x, i0, hl);
+                    g1[s] = gather_x<HALO>(x, c[s].y, i0, hl);
                 }
             }
 #pragma unroll
@@ -162,8 +175,8 @@ __global__ __launch_bounds__(CGH_BLOCK) void spmv_ell_r2(int64_t n, int Krt, con
                     c = load_cols<NT, DICT>(cols, tab, n, s, i0);
                 }
                 const d2_t    v = stream_load<NT>(reinterpret_cast<const d2_t *>(vals + (int64_t)s * n + i0));
-                const double  g0 = x[c.x >= 0 ? (int64_t)c.x : i0];
-                const double  g1 = x[c.y >= 0 ? (int64_t)c.y : i0];
+                const double  g0 = gather_x<HALO>(x, c.x, i0, hl);
+                const double  g1 = gather_x<HALO>(x, c.y, i0, hl);
                 const double  t0 = madd_rn(a0, v.x, g0);
                 const double  t1 = madd_rn(a1, v.y, g1);
                 a0 = c.x >= 0 ? t0 : a0;
@@ -225,15 +238,15 @@ __global__ __launch_bounds__(CGH_BLOCK) void spmv_ell_r1(int64_t n, int K, const
 
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
-template <int DOT, int VAR, int DICT = 0>
+template <int DOT, int VAR, int DICT = 0, int HALO = 0>
 void launch_r2(int K, int grid, hipStream_t s, int64_t n, const double *diag, const double *vals, const void *cols,
                const int *off_tab, const double *x, double *y, double *partials, const int *done, int64_t rb, int64_t re,
-               int64_t rb2, int64_t re2)
+               int64_t rb2, int64_t re2, cgh_ll_halo hl = cgh_ll_halo{nullptr, 0, 0u, nullptr})
 {
 #define CGH_ELL_CASE(KK)                                                                                       \
     case KK:                                                                                                   \
-        hipLaunchKernelGGL((spmv_ell_r2<KK, DOT, VAR, DICT>), dim3(grid), dim3(CGH_BLOCK), 0, s, n, K, diag, vals, cols, \
-                           off_tab, x, y, partials, done, g_cgh.sweep_reverse, rb, re, rb2, re2);                     \
+        hipLaunchKernelGGL((spmv_ell_r2<KK, DOT, VAR, DICT, HALO>), dim3(grid), dim3(CGH_BLOCK), 0, s, n, K, diag, vals, cols, \
+                           off_tab, x, y, partials, done, g_cgh.sweep_reverse, rb, re, rb2, re2, hl);                 \
         break;
     static const int generic = getenv("CGH_ELL_GENERIC") ? atoi(getenv("CGH_ELL_GENERIC")) : 0;
     switch (generic ? -1 : K) {
@@ -248,8 +261,8 @@ void launch_r2(int K, int grid, hipStream_t s, int64_t n, const double *diag, co
         CGH_ELL_CASE(13)
         CGH_ELL_CASE(26)
     default:
-        hipLaunchKernelGGL((spmv_ell_r2<0, DOT, VAR, DICT>), dim3(grid), dim3(CGH_BLOCK), 0, s, n, K, diag, vals, cols, off_tab,
-                           x, y, partials, done, g_cgh.sweep_reverse, rb, re, rb2, re2);
+        hipLaunchKernelGGL((spmv_ell_r2<0, DOT, VAR, DICT, HALO>), dim3(grid), dim3(CGH_BLOCK), 0, s, n, K, diag, vals, cols, off_tab,
+                           x, y, partials, done, g_cgh.sweep_reverse, rb, re, rb2, re2, hl);
     }
 #undef CGH_ELL_CASE
 }
@@ -455,6 +468,11 @@ int cgh_launch_spmv_ell_range(const cgh_matrix *m, const double *x, double *y, d
     return cgh_launch_spmv_ell_range2(m, x, y, dot_partials, grid_out, done, s, rb, re, 0, 0);
 }
 
+bool cgh_spmv_ell_halo_capable(const cgh_matrix *m, const double *x, double *y, int64_t rb, int64_t re, int64_t rb2, int64_t re2)
+{
+    return ell_vector_path(m, x, y) && rb % 2 == 0 && re % 2 == 0 && rb2 % 2 == 0 && re2 % 2 == 0;
+}
+
 // Two row ranges in one launch (second may be empty).
 int cgh_launch_spmv_ell_range2(const cgh_matrix *m, const double *x, double *y, double *dot_partials, int *grid_out,
                                const int *done, hipStream_t s, int64_t rb, int64_t re, int64_t rb2, int64_t re2)
@@ -548,6 +566,34 @@ int cgh_launch_spmv_ell_range2(const cgh_matrix *m, const double *x, double *y, 
             hipLaunchKernelGGL((spmv_ell_r1<false>), dim3(grid), dim3(CGH_BLOCK), 0, s, m->n, m->K, m->diag, m->vals,
                                m->cols, x, y, (double *)nullptr, done, rb, re);
     }
+    CGH_HIP(hipGetLastError());
+    return CGH_OK;
+}
+
+// Rows [rb,re) + [rb2,re2) of a multi-GPU block whose halo entries (column ids >= hl->nl) are read from the deposit
+// buffer instead of x's tail; partials of x.y are always produced.  Returns CGH_EINVAL if this matrix cannot take
+// the vector path (the caller then unpacks the deposit into x's tail and uses cgh_launch_spmv_ell_range2).
+int cgh_launch_spmv_ell_halo(const cgh_matrix *m, const double *x, double *y, double *dot_partials, int *grid_out,
+                             const int *done, hipStream_t s, int64_t rb, int64_t re, int64_t rb2, int64_t re2,
+                             const cgh_ll_halo *hl)
+{
+    if (re < rb) re = rb;
+    if (re2 < rb2) re2 = rb2;
+    const int64_t rows = (re - rb) + (re2 - rb2);
+    const int grid = ell_grid_rows(rows);
+    if (grid_out) *grid_out = rows > 0 ? grid : 0;
+    if (!cgh_spmv_ell_halo_capable(m, x, y, rb, re, rb2, re2) || !dot_partials) return CGH_EINVAL;
+    if (rows <= 0) return CGH_OK;
+    if (m->dict_state == 0) ell_dict_try_build(m, s);
+    if (m->dict_state == 1 && m->dict_mode == 2)
+        launch_r2<1, VAR_DEFAULT, 2, 1>(m->K, grid, s, m->n, m->diag, m->vals, m->cols8, m->off_tab, x, y, dot_partials, done, rb, re, rb2,
+                                        re2, *hl);
+    else if (m->dict_state == 1)
+        launch_r2<1, VAR_DEFAULT, 1, 1>(m->K, grid, s, m->n, m->diag, m->vals, m->cols8, m->off_tab, x, y, dot_partials, done, rb, re, rb2,
+                                        re2, *hl);
+    else
+        launch_r2<1, VAR_DEFAULT, 0, 1>(m->K, grid, s, m->n, m->diag, m->vals, m->cols, nullptr, x, y, dot_partials, done, rb, re, rb2, re2,
+                                        *hl);
     CGH_HIP(hipGetLastError());
     return CGH_OK;
 }

@@ -233,6 +233,10 @@ int     cgh_dist_download_local(const cgh_dist *d, double *diag, double *ell_val
 int     cgh_dist_halo_descriptor(cgh_dist *d, char out_512_bytes[512]);
 int     cgh_dist_halo_connect(cgh_dist *d, const char *descriptors_nranks_x_512_bytes);
 int     cgh_dist_halo_is_p2p(const cgh_dist *d);
+/* One-GPU timing harness: an inner slab (created as rank r of N under a ONE-rank communicator) becomes its own two
+ * neighbours, i.e. the slab's operator closed periodically in z; per-iteration kernels, bytes and waits are those of an
+ * inner rank of the N-GPU run, minus the xGMI hop.  No reference counterpart. */
+int     cgh_dist_loopback(cgh_dist *d);
 
 /* ---- timing helpers (benchmarks) ---------------------------------------- */
 /* Launch `reps` back-to-back SpMVs and return the average kernel time in ms (HIP events on the launch stream). */
