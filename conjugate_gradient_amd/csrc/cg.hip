@@ -315,7 +315,9 @@ static int enqueue_iterations(cgh_solver *sv, int count, int time_kernels, bool 
             hipLaunchKernelGGL((cg_update_xp<1, 3>), dim3(vg), dim3(CGH_BLOCK), 0, s, n, d_x, (const double *)dr, dp,
                                (const double *)dB, vg, dh, iter, tol, dd, rev1, (const double *)nullptr);
         } else {
-            static const int vv = getenv("CGH_VEC_VARIANT") ? atoi(getenv("CGH_VEC_VARIANT")) & 15 : 3;
+            // non-temporal loads + x store (3) unless the working set is within twice the Infinity Cache (0): see cgh_fits_llc
+            static const int vv_env = getenv("CGH_VEC_VARIANT") ? atoi(getenv("CGH_VEC_VARIANT")) & 15 : -1;
+            const int        vv = vv_env >= 0 ? vv_env : (sv->m->layout == CGH_LAYOUT_ELL && cgh_fits_llc(sv->m, 2.0) ? 0 : 3);
 #define CGH_VEC_VAR(V)                                                                                                 \
     case V:                                                                                                            \
         hipLaunchKernelGGL((cg_update_r<0, V>), dim3(vg), dim3(CGH_BLOCK), 0, s, n, dr, (const double *)dAp,       \

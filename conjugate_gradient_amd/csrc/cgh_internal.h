@@ -125,6 +125,7 @@ int64_t cgh_xsum_cells(const cgh_xsum *w);
 
 // p2p.hip -- scalar all-reduce over peer stores (multi-GPU path); W-interleaved partials in, W sums out
 int cgh_p2p_launch(int W, const double *partials, int count, double *out, hipStream_t s);
+bool cgh_fits_llc(const cgh_matrix *m, double times);   // spmv_ell.hip: one iteration's working set fits `times` Infinity Caches
 struct cgh_link;
 struct cgh_ll_halo;
 int cgh_p2p_link(cgh_link *L);   // the connected mailboxes as the iteration's kernels see them (halo_ll.h)

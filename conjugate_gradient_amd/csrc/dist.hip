@@ -14,8 +14,8 @@
 // not a ring; the all-reduces carry 8-16 bytes and are pure latency.
 //
 // That is the FALLBACK.  When the ranks can map each other's memory (hipIpc over xGMI; cgh_comm_init tries it and all
-// ranks agree), RCCL only bootstraps and an iteration is four kernels on ONE stream with no event and no library call:
-//     s: SpMV interior rows ; SpMV boundary rows, halo columns read from the deposit buffer the neighbours wrote into ;
+// ranks agree), RCCL only bootstraps and an iteration is three kernels on ONE stream with no event and no library call:
+//     s: SpMV, the rows with halo columns last: they read those from the deposit buffer the neighbours wrote into ;
 //        dist_update_r  (prologue: p.Ap all-reduced through the peers' mailboxes) ;
 //        dist_update_xp (prologue: r.r, |r|_1 all-reduced ; epilogue: boundary rows of the new p pushed to the neighbours)
 // (halo_ll.h, dist_kernels.h; measured: a cross-stream event costs ~11 us each way, a small kernel ~5 us.)
@@ -936,7 +936,7 @@ int cgh_dist_iterate(cgh_dist *d, int count, int time_kernels)
     }
     hipStream_t   s = g_cgh.stream, c = g_cgh.comm_stream;
     const int64_t nl = d->n_loc;
-    static const bool one_spmv = getenv("CGH_DIST_ONE_SPMV") && atoi(getenv("CGH_DIST_ONE_SPMV")) != 0;
+    static const bool one_spmv = !(getenv("CGH_DIST_ONE_SPMV") && atoi(getenv("CGH_DIST_ONE_SPMV")) == 0);
     for (int k = 0; k < count; ++k) {
         const int  iter = ++d->queued;
         const bool halo = !d->nbs.empty(), direct = halo && g_rccl.p2p && d->halo_p2p, folded = g_rccl.p2p;
@@ -963,8 +963,10 @@ int cgh_dist_iterate(cgh_dist *d, int count, int time_kernels)
             const cgh_ll_halo hl = halo_view(d, iter);
             const int64_t     a = d->int_begin, b = d->int_end;
             int               g = 0;
-            if (d->ll_spmv && one_spmv) {  // experiment: one launch over all rows
-                rc = cgh_launch_spmv_ell_halo(&d->mat, d->p, d->Ap, d->partA, &g, d->done, s, 0, nl, 0, 0, &hl);
+            if (d->ll_spmv && one_spmv) {
+                // ONE launch over all rows (1.8 us less than two at 2M rows), walked so that the rows with halo columns
+                // come last: interior [a,b) and upper boundary [b,nl) first, lower boundary [0,a) at the end
+                rc = cgh_launch_spmv_ell_halo(&d->mat, d->p, d->Ap, d->partA, &g, d->done, s, a, nl, 0, a, &hl);
                 if (rc) return rc;
                 cnt = g;
             } else {
@@ -996,8 +998,13 @@ int cgh_dist_iterate(cgh_dist *d, int count, int time_kernels)
             if (rc) return rc;
             L.self = d->loopback ? 1 : 0;
             L.tag = cgh_ll_tag(d->epoch, 2u * (unsigned)iter);
-            hipLaunchKernelGGL(dist_update_r, dim3(d->vgrid), dim3(CGH_BLOCK), 0, s, nl, d->r, (const double *)d->Ap, (const double *)d->partA,
-                               cnt, d->partB, d->hist, iter, (const int *)d->done, L);
+            const bool cached = cgh_fits_llc(&d->mat, 2.0);  // hints off when the caches can hold the vectors between kernels
+            if (cached)
+                hipLaunchKernelGGL(dist_update_r<0>, dim3(d->vgrid), dim3(CGH_BLOCK), 0, s, nl, d->r, (const double *)d->Ap,
+                                   (const double *)d->partA, cnt, d->partB, d->hist, iter, (const int *)d->done, L);
+            else
+                hipLaunchKernelGGL(dist_update_r<3>, dim3(d->vgrid), dim3(CGH_BLOCK), 0, s, nl, d->r, (const double *)d->Ap,
+                                   (const double *)d->partA, cnt, d->partB, d->hist, iter, (const int *)d->done, L);
             L.tag = cgh_ll_tag(d->epoch, 2u * (unsigned)iter + 1u);
             cgh_pushes P;
             memset(&P, 0, sizeof P);
@@ -1011,8 +1018,12 @@ int cgh_dist_iterate(cgh_dist *d, int count, int time_kernels)
                 }
                 d->pushed_iter = iter + 1;
             }
-            hipLaunchKernelGGL(dist_update_xp, dim3(d->vgrid), dim3(CGH_BLOCK), 0, s, nl, d->x, (const double *)d->r, d->p,
-                               (const double *)d->partB, d->vgrid, d->hist, iter, d->tol, d->done, L, P);
+            if (cached)
+                hipLaunchKernelGGL(dist_update_xp<0>, dim3(d->vgrid), dim3(CGH_BLOCK), 0, s, nl, d->x, (const double *)d->r, d->p,
+                                   (const double *)d->partB, d->vgrid, d->hist, iter, d->tol, d->done, L, P);
+            else
+                hipLaunchKernelGGL(dist_update_xp<3>, dim3(d->vgrid), dim3(CGH_BLOCK), 0, s, nl, d->x, (const double *)d->r, d->p,
+                                   (const double *)d->partB, d->vgrid, d->hist, iter, d->tol, d->done, L, P);
         } else {
             hipLaunchKernelGGL(reduce_local<1>, dim3(1), dim3(CGH_BLOCK), 0, s, (const double *)d->partA, cnt, d->gs_local);
             CGH_NCCL(g_rccl.AllReduce(d->gs_local, d->gs, 1, ncclDouble, ncclSum, g_rccl.comm, s));

@@ -11,14 +11,17 @@
 //   halo_push_ll     the same push as a kernel of its own: the first exchange of a solve (p = r0 comes from cg_init_rp)
 //                    and send lists that are not contiguous
 //   halo_pull_ll     deposit slot -> halo tail of p, for SpMV paths that cannot read the deposit themselves
-// Per iteration an inner rank launches: interior SpMV, boundary SpMV (reads the deposit), dist_update_r,
-// dist_update_xp -- four kernels on one stream, no events, no library call.
+// Per iteration a rank launches the SpMV (rows with halo columns last; they read the deposit), dist_update_r and
+// dist_update_xp -- three kernels on one stream, as on a single GPU; no events, no library call.
 #pragma once
 #include "cg_kernels.h"
 #include "halo_ll.h"
 
 namespace {
 
+constexpr int DIST_PRE = 2;  // chunks per workgroup whose loads precede the prologue
+
+template <int VV>
 __global__ __launch_bounds__(CGH_BLOCK) void dist_update_r(int64_t n, double *__restrict__ r, const double *__restrict__ Ap,
                                                           const double *__restrict__ pAp_partials, int pAp_count,
                                                           double *__restrict__ out_partials, double *hist, int iter,
@@ -26,20 +29,41 @@ __global__ __launch_bounds__(CGH_BLOCK) void dist_update_r(int64_t n, double *__
 {
     __shared__ double lds[4];
     __shared__ double ex[2 * CGH_LINK_MAX_RANKS];
+    const int64_t pairs = n >> 1;
+    const int64_t chunks = (pairs + CGH_BLOCK - 1) / CGH_BLOCK;
+    // The first DIST_PRE chunks' loads are issued BEFORE the prologue: at 2M rows per GPU a workgroup owns two chunks,
+    // and the HBM latency then overlaps the partial sums and the mailbox round trip instead of following them.
+    double2 rv[DIST_PRE], av[DIST_PRE];
+#pragma unroll
+    for (int j = 0; j < DIST_PRE; ++j) {
+        const int64_t k = ((int64_t)blockIdx.x + (int64_t)j * gridDim.x) * CGH_BLOCK + threadIdx.x;
+        if (k < pairs) {
+            rv[j] = ld2<VV>(r, k);
+            av[j] = ld2<VV>(Ap, k);
+        }
+    }
     if (*done != 0) return;  // frozen on every rank alike (the flag derives from all-reduced scalars): nobody exchanges
     double mine[1] = {block_sum_partials(pAp_partials, pAp_count, 1, lds)}, pAp[1];
     link_allreduce<1>(L, mine, pAp, ex);
     const double alpha = hist[(size_t)(iter - 1) * HIST + 1] / pAp[0];
     if (blockIdx.x == 0 && threadIdx.x == 0) hist[(size_t)iter * HIST + 2] = alpha;
-    const double  nalpha = -alpha;
-    double        rr = 0.0, l1 = 0.0;
-    const int64_t pairs = n >> 1;
-    const int64_t chunks = (pairs + CGH_BLOCK - 1) / CGH_BLOCK;
-    for (int64_t cc = blockIdx.x; cc < chunks; cc += gridDim.x) {
+    const double nalpha = -alpha;
+    double       rr = 0.0, l1 = 0.0;
+#pragma unroll
+    for (int j = 0; j < DIST_PRE; ++j) {
+        const int64_t k = ((int64_t)blockIdx.x + (int64_t)j * gridDim.x) * CGH_BLOCK + threadIdx.x;
+        if (k < pairs) {
+            const double2 rn = make_double2(madd_rn(rv[j].x, nalpha, av[j].x), madd_rn(rv[j].y, nalpha, av[j].y));  // vec.c:88-94, cg.c:469
+            st2<false>(r, k, rn.x, rn.y);
+            rr += rn.x * rn.x + rn.y * rn.y;
+            l1 += fabs(rn.x) + fabs(rn.y);
+        }
+    }
+    for (int64_t cc = (int64_t)blockIdx.x + (int64_t)DIST_PRE * gridDim.x; cc < chunks; cc += gridDim.x) {
         const int64_t k = cc * CGH_BLOCK + threadIdx.x;
         if (k >= pairs) continue;
-        const double2 rv = ld2<3>(r, k), av = ld2<3>(Ap, k);
-        const double2 rn = make_double2(madd_rn(rv.x, nalpha, av.x), madd_rn(rv.y, nalpha, av.y));  // vec.c:88-94, cg.c:469
+        const double2 r2 = ld2<VV>(r, k), a2 = ld2<VV>(Ap, k);
+        const double2 rn = make_double2(madd_rn(r2.x, nalpha, a2.x), madd_rn(r2.y, nalpha, a2.y));
         st2<false>(r, k, rn.x, rn.y);
         rr += rn.x * rn.x + rn.y * rn.y;
         l1 += fabs(rn.x) + fabs(rn.y);
@@ -66,12 +90,25 @@ __device__ __forceinline__ void push_row(const cgh_pushes &P, int64_t row, doubl
     }
 }
 
+template <int VV>
 __global__ __launch_bounds__(CGH_BLOCK) void dist_update_xp(int64_t n, double *__restrict__ x, const double *__restrict__ r,
                                                            double *__restrict__ p, const double *__restrict__ partials, int count,
                                                            double *hist, int iter, double tol, int *done, cgh_link L, cgh_pushes P)
 {
     __shared__ double lds[4];
     __shared__ double ex[2 * CGH_LINK_MAX_RANKS];
+    const int64_t pairs = n >> 1;
+    const int64_t chunks = (pairs + CGH_BLOCK - 1) / CGH_BLOCK;
+    double2       xv[DIST_PRE], rv[DIST_PRE], pv[DIST_PRE];  // loads before the prologue, as in dist_update_r
+#pragma unroll
+    for (int j = 0; j < DIST_PRE; ++j) {
+        const int64_t k = ((int64_t)blockIdx.x + (int64_t)j * gridDim.x) * CGH_BLOCK + threadIdx.x;
+        if (k < pairs) {
+            xv[j] = ld2<VV>(x, k);
+            rv[j] = ld2<VV>(r, k);
+            pv[j] = ld2<VV>(p, k);
+        }
+    }
     // The flag may name THIS iteration: workgroup 0 of this very launch publishes the verdict (below) while later
     // workgroups are still starting -- they go on and reach the same verdict (the peers' messages stay in the mailbox).
     const int frozen_at = *done;
@@ -90,28 +127,39 @@ __global__ __launch_bounds__(CGH_BLOCK) void dist_update_xp(int64_t n, double *_
         hist[(size_t)iter * HIST + 3] = conv ? NAN : beta;
         done[2] = iter;
     }
-    const int64_t pairs = n >> 1;
-    const int64_t chunks = (pairs + CGH_BLOCK - 1) / CGH_BLOCK;
     if (conv) {
         // the reference updates x, then returns before touching p (cg.c:467-485); every workgroup (on every rank) reaches
         // the same verdict from the same scalars, workgroup 0 publishes it for the launches behind this one
         for (int64_t cc = blockIdx.x; cc < chunks; cc += gridDim.x) {
             const int64_t k = cc * CGH_BLOCK + threadIdx.x;
             if (k >= pairs) continue;
-            const double2 xv = ld2<3>(x, k), pv = ld2<3>(p, k);
-            st2<true>(x, k, madd_rn(xv.x, alpha, pv.x), madd_rn(xv.y, alpha, pv.y));
+            const double2 x2 = ld2<VV>(x, k), p2 = ld2<VV>(p, k);
+            st2<(VV & 2) != 0>(x, k, madd_rn(x2.x, alpha, p2.x), madd_rn(x2.y, alpha, p2.y));
         }
         if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) x[n - 1] = madd_rn(x[n - 1], alpha, p[n - 1]);
         if (blockIdx.x == 0 && threadIdx.x == 0) *done = iter;
         return;
     }
-    for (int64_t cc = blockIdx.x; cc < chunks; cc += gridDim.x) {
+#pragma unroll
+    for (int j = 0; j < DIST_PRE; ++j) {
+        const int64_t k = ((int64_t)blockIdx.x + (int64_t)j * gridDim.x) * CGH_BLOCK + threadIdx.x;
+        if (k < pairs) {
+            // reference vec_axpy: out = a + alpha*b (vec.c:88-94): x += alpha p (cg.c:467), p = r + beta p (cg.c:489)
+            st2<(VV & 2) != 0>(x, k, madd_rn(xv[j].x, alpha, pv[j].x), madd_rn(xv[j].y, alpha, pv[j].y));
+            const double p0 = madd_rn(rv[j].x, beta, pv[j].x), p1 = madd_rn(rv[j].y, beta, pv[j].y);
+            st2<false>(p, k, p0, p1);
+            if (P.n > 0) {
+                push_row(P, 2 * k, p0);
+                push_row(P, 2 * k + 1, p1);
+            }
+        }
+    }
+    for (int64_t cc = (int64_t)blockIdx.x + (int64_t)DIST_PRE * gridDim.x; cc < chunks; cc += gridDim.x) {
         const int64_t k = cc * CGH_BLOCK + threadIdx.x;
         if (k >= pairs) continue;
-        const double2 xv = ld2<3>(x, k), rv = ld2<3>(r, k), pv = ld2<3>(p, k);
-        // reference vec_axpy: out = a + alpha*b (vec.c:88-94): x += alpha p (cg.c:467), p = r + beta p (cg.c:489)
-        st2<true>(x, k, madd_rn(xv.x, alpha, pv.x), madd_rn(xv.y, alpha, pv.y));
-        const double p0 = madd_rn(rv.x, beta, pv.x), p1 = madd_rn(rv.y, beta, pv.y);
+        const double2 x2 = ld2<VV>(x, k), r2 = ld2<VV>(r, k), p2 = ld2<VV>(p, k);
+        st2<(VV & 2) != 0>(x, k, madd_rn(x2.x, alpha, p2.x), madd_rn(x2.y, alpha, p2.y));
+        const double p0 = madd_rn(r2.x, beta, p2.x), p1 = madd_rn(r2.y, beta, p2.y);
         st2<false>(p, k, p0, p1);
         if (P.n > 0) {
             push_row(P, 2 * k, p0);

@@ -447,6 +447,17 @@ static inline bool ell_vector_path(const cgh_matrix *m, const double *x, const d
            (reinterpret_cast<uintptr_t>(m->cols) & 7u) == 0;
 }
 
+// Does one CG iteration's working set on this matrix (matrix + the four vectors) fit the Infinity Cache with room to
+// spare (`times` = 1), or `times` of them?  CGH_LLC_MB sets the limit (default 224; 0 = never).  Measured (us/iteration,
+// 7-point, hints on -> off): 1M rows 38.9 -> 34.2, 2.1M 59.9 -> 53.7; at 4.2M (394 MB) only the vector kernels gain
+// (106.9 -> 103.1) and the SpMV loses; at 8.4M everything loses (202.9 -> 233.2).
+bool cgh_fits_llc(const cgh_matrix *m, double times)
+{
+    static const double limit = (getenv("CGH_LLC_MB") ? atof(getenv("CGH_LLC_MB")) : 224.0) * 1048576.0;
+    const double per_entry = m->dict_state == 1 ? 9.0 : 12.0;
+    return (double)m->stored * per_entry + (double)m->n * 8.0 * 5.0 <= limit * times;
+}
+
 static int ell_grid_rows(int64_t rows)
 {
     // tiles of 512 rows (256 threads x 2 rows); grid a multiple of 8 so tile%8 -> XCD group is stable
@@ -514,8 +525,11 @@ int cgh_launch_spmv_ell_range2(const cgh_matrix *m, const double *x, double *y, 
             return CGH_OK;
         }
         if (m->dict_state == 1) {
-            // CGH_ELL_VARIANT=3: cached (not non-temporal) y store, for experiments
-            static const int dvar = getenv("CGH_ELL_VARIANT") && atoi(getenv("CGH_ELL_VARIANT")) == 3 ? 3 : VAR_DEFAULT;
+            // Variant: 11 = non-temporal matrix loads and y store (the matrix streams through once, x stays in L2); 1 = plain
+            // loads and stores, for working sets the 256 MiB Infinity Cache can hold from one kernel to the next (there the
+            // hints cost 4-8 % of an iteration: tools/quick_mall.py); CGH_ELL_VARIANT=1|3|11 overrides (3: NT loads only)
+            static const int forced = getenv("CGH_ELL_VARIANT") ? atoi(getenv("CGH_ELL_VARIANT")) : -1;
+            const int        dvar = (forced == 1 || forced == 3 || forced == 11) ? forced : (cgh_fits_llc(m, 1.0) ? 1 : VAR_DEFAULT);
 #define CGH_ELL_DICT_LAUNCH(V, MODE)                                                                                       \
     if (dot_partials)                                                                                                      \
         launch_r2<true, V, MODE>(m->K, grid, s, m->n, m->diag, m->vals, m->cols8, m->off_tab, x, y, dot_partials, done, rb, re, \
@@ -526,11 +540,15 @@ int cgh_launch_spmv_ell_range2(const cgh_matrix *m, const double *x, double *y, 
             if (m->dict_mode == 2) {
                 if (dvar == 3) {
                     CGH_ELL_DICT_LAUNCH(3, 2)
+                } else if (dvar == 1) {
+                    CGH_ELL_DICT_LAUNCH(1, 2)
                 } else {
                     CGH_ELL_DICT_LAUNCH(VAR_DEFAULT, 2)
                 }
             } else if (dvar == 3) {
                 CGH_ELL_DICT_LAUNCH(3, 1)
+            } else if (dvar == 1) {
+                CGH_ELL_DICT_LAUNCH(1, 1)
             } else {
                 CGH_ELL_DICT_LAUNCH(VAR_DEFAULT, 1)
             }
@@ -538,10 +556,11 @@ int cgh_launch_spmv_ell_range2(const cgh_matrix *m, const double *x, double *y, 
             CGH_HIP(hipGetLastError());
             return CGH_OK;
         }
-        static const int var = [] {
-            const int v = getenv("CGH_ELL_VARIANT") ? atoi(getenv("CGH_ELL_VARIANT")) : VAR_DEFAULT;
-            return (v == 0 || v == 1 || v == 2 || v == 3 || v == 7 || v == 11) ? v : VAR_DEFAULT;
+        static const int var_env = [] {
+            const int v = getenv("CGH_ELL_VARIANT") ? atoi(getenv("CGH_ELL_VARIANT")) : -1;
+            return (v == 0 || v == 1 || v == 2 || v == 3 || v == 7 || v == 11) ? v : -1;
         }();
+        const int var = var_env >= 0 ? var_env : (cgh_fits_llc(m, 1.0) ? 1 : VAR_DEFAULT);
 #define CGH_ELL_VAR(V)                                                                                                  \
     case V:                                                                                                             \
         if (dot_partials)                                                                                               \
@@ -585,15 +604,21 @@ int cgh_launch_spmv_ell_halo(const cgh_matrix *m, const double *x, double *y, do
     if (!cgh_spmv_ell_halo_capable(m, x, y, rb, re, rb2, re2) || !dot_partials) return CGH_EINVAL;
     if (rows <= 0) return CGH_OK;
     if (m->dict_state == 0) ell_dict_try_build(m, s);
-    if (m->dict_state == 1 && m->dict_mode == 2)
-        launch_r2<1, VAR_DEFAULT, 2, 1>(m->K, grid, s, m->n, m->diag, m->vals, m->cols8, m->off_tab, x, y, dot_partials, done, rb, re, rb2,
-                                        re2, *hl);
-    else if (m->dict_state == 1)
-        launch_r2<1, VAR_DEFAULT, 1, 1>(m->K, grid, s, m->n, m->diag, m->vals, m->cols8, m->off_tab, x, y, dot_partials, done, rb, re, rb2,
-                                        re2, *hl);
-    else
-        launch_r2<1, VAR_DEFAULT, 0, 1>(m->K, grid, s, m->n, m->diag, m->vals, m->cols, nullptr, x, y, dot_partials, done, rb, re, rb2, re2,
-                                        *hl);
+#define CGH_ELL_HALO_LAUNCH(V)                                                                                                 \
+    if (m->dict_state == 1 && m->dict_mode == 2)                                                                               \
+        launch_r2<1, V, 2, 1>(m->K, grid, s, m->n, m->diag, m->vals, m->cols8, m->off_tab, x, y, dot_partials, done, rb, re, rb2, re2, \
+                              *hl);                                                                                            \
+    else if (m->dict_state == 1)                                                                                               \
+        launch_r2<1, V, 1, 1>(m->K, grid, s, m->n, m->diag, m->vals, m->cols8, m->off_tab, x, y, dot_partials, done, rb, re, rb2, re2, \
+                              *hl);                                                                                            \
+    else                                                                                                                       \
+        launch_r2<1, V, 0, 1>(m->K, grid, s, m->n, m->diag, m->vals, m->cols, nullptr, x, y, dot_partials, done, rb, re, rb2, re2, *hl);
+    if (cgh_fits_llc(m, 1.0)) {
+        CGH_ELL_HALO_LAUNCH(1)
+    } else {
+        CGH_ELL_HALO_LAUNCH(VAR_DEFAULT)
+    }
+#undef CGH_ELL_HALO_LAUNCH
     CGH_HIP(hipGetLastError());
     return CGH_OK;
 }
