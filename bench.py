@@ -99,6 +99,43 @@ def cpu_baseline(A, b_dev, budget_s=15.0):
                       "its SpMV alone: %.3f s = %.2f GB/s algorithmic" % (iters, n, dt, t_spmv, alg / t_spmv / 1e9)}
 
 
+def rehearse_inner_rank(nx, ny, nz, points, ranks, one_gpu_rate):
+    """What ONE GPU can say about the N-GPU run: the z-slab of an inner rank (rank 3 of 8) of the same matrix, with this
+    GPU as both of its neighbours (cgh_dist_loopback: deposits, tags, mailbox all-reduces and waits as between GPUs, the
+    xGMI hop itself missing).  Reported beside the headline, never as `value`; the driver's 2/4/8-GPU runs are the
+    measurement."""
+    L = cga.lib()
+    try:
+        buf = C.create_string_buffer(64)
+        cga.check(L.cgh_p2p_local_handle(buf))
+        cga.check(L.cgh_p2p_connect(1, 0, buf.raw))
+        cga.check(L.cgh_comm_init_local(1, 0))
+        nzl = nz // ranks
+        nl = nx * ny * nzl
+        b = cga.DeviceVector(nl); x = cga.DeviceVector(nl)
+        D = cga.DistRank.poisson(nx, ny, nz, points, SEED, ranks, 3, b)
+        D.loopback()
+        iters = 300
+        D.start(b, x, -1.0, 2 * iters + 2)
+        D.iterate(iters, 0)
+        cga.check(L.cgh_sync())
+        t0 = time.perf_counter()
+        D.iterate(iters, 0)
+        cga.check(L.cgh_sync())
+        us = (time.perf_counter() - t0) / iters * 1e6
+        hist = D.history(0, 2 * iters + 1)
+        D.free()
+        ok = bool(np.all(np.isfinite(hist[:, 0]))) and L.cgh_p2p_error() == 0
+        return {"what": "rank 3 of %d of the same matrix (%dx%dx%d slab, %d rows, two %d-entry halo planes) with this GPU as both "
+                        "neighbours; peer-to-peer transport, xGMI hop missing" % (ranks, nx, ny, nzl, nl, nx * ny),
+                "us_per_iteration": us, "iterations_per_s": 1e6 / us, "ratio_to_one_gpu": 1e6 / us / one_gpu_rate,
+                "finite": ok}
+    except Exception as e:  # noqa: BLE001  (a rehearsal must not cost the bench its line)
+        return {"error": str(e)}
+    finally:
+        L.cgh_comm_destroy()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -201,6 +238,8 @@ def main():
     sv.free()
     out["parity_mode"] = {"value": ps / pdt, "unit": "iterations/s", "ms_per_step": pdt / ps * 1e3, "steps": ps,
                           "note": "strict=1: dots and L1 norm in the reference's summation order (bit-identical trajectory)"}
+    if args.workload == "p7_256":
+        out["multi_gpu_rehearsal"] = rehearse_inner_rank(nx, ny, nz, points, 8, args.steps / dt)
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(A, b)
     print(json.dumps(out), flush=True)

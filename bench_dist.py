@@ -185,15 +185,16 @@ def run(args, rank, world, local_rank, shape, seed):
             "config": {"workload": "%s: 3-D %d-point Poisson %dx%dx%d, %d rows, slot-major ELL, unpreconditioned CG, "
                                    "z-slab row blocks over %d GPUs, %s" % (
                                        args.workload, points, nx, ny, nz, m["n"], world,
-                                       "p-halo by peer-to-peer deposits over xGMI overlapped with the interior SpMV, the 2 scalar "
-                                       "all-reduces per iteration as peer-to-peer mailbox kernels (RCCL: bootstrap and fallback)"
+                                       "3 kernels per iteration on one stream: p-halo pushed over xGMI by the p-update kernel into "
+                                       "tagged deposits the SpMV reads (halo rows last), the 2 scalar all-reduces folded into the "
+                                       "prologues of the kernels that consume them (RCCL: bootstrap and fallback)"
                                        if p2p else
                                        "p-halo by ncclSend/Recv overlapped with the interior SpMV, 2 ncclAllReduce per iteration"),
                        "rows": m["n"], "nnz_offdiag": m["nnz_off"], "parallelism": "row-block x%d" % world,
                        "scalar_allreduce": path, "halo_exchange": m["halo"], "transport_probe": probe,
                        "iter_GBs_algorithmic": (12 * m["nnz_off"] + 96 * m["n"]) / (m["ms_step"] * 1e-3) / 1e9,
                        "residual_l1_half_first_last": m["res"]},
-            "roofline": {"bound": "hbm", "kernel": "spmv_ell_r2 (interior + boundary launches, incl. exposed halo wait; slowest rank)",
+            "roofline": {"bound": "hbm", "kernel": "spmv_ell_r2 (all local rows, halo rows last, incl. exposed halo wait; slowest rank)",
                          "achieved": m["achieved"], "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
                          "frac": m["achieved"] / (HBM_PEAK_GBS * world), "bytes_per_launch": int(m["alg_spmv"]),
                          "ms_per_launch": m["spmv_ms"], "traffic": None},

@@ -1,6 +1,8 @@
 """One rank of the multi-PROCESS test of the distributed CG loop (tests/test_gpu_dist.py): all ranks share the one GPU
 of the test box, so the transport is the peer-to-peer one throughout (mailbox all-reduce + deposit-buffer halo); handles
-and descriptors travel through files.  python dist_worker.py <rank> <nranks> <dir> <nx> <ny> <nz> <points> <max_iter> <tol>
+and descriptors travel through files.
+    python dist_worker.py <rank> <nranks> <dir> <nx> <ny> <nz> <points> <max_iter> <tol>     z-slabs from the device generator
+    python dist_worker.py <rank> <nranks> <dir> tag <golden input> 0 0 <max_iter> <tol>      row blocks of a stored system
 Writes hist_<rank>.npy and x_<rank>.npy."""
 import ctypes as C
 import os
@@ -13,8 +15,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import conjugate_gradient_amd as cga  # noqa: E402
 
 rank, nranks, d = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
-nx, ny, nz, points, max_iter = (int(v) for v in sys.argv[4:9])
-tol = float(sys.argv[9])
+tag = sys.argv[5] if sys.argv[4] == "tag" else None
+nx, ny, nz, points = (0, 0, 0, 0) if tag else (int(v) for v in sys.argv[4:8])
+max_iter, tol = int(sys.argv[8]), float(sys.argv[9])
 
 
 def publish(name, data):
@@ -48,9 +51,18 @@ publish("handle%d" % rank, buf.raw)
 cga.check(L.cgh_p2p_connect(nranks, rank, collect("handle", 64)), "p2p connect")
 cga.check(L.cgh_comm_init_local(nranks, rank), "comm_init_local")
 
-nl = nx * ny * (nz * (rank + 1) // nranks - nz * rank // nranks)
-b = cga.DeviceVector(nl); x = cga.DeviceVector(nl)
-D = cga.DistRank.poisson(nx, ny, nz, points, 0x5EED0001, nranks, rank, b)
+if tag:
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from gpu_common import inputs  # noqa: E402
+    sy = inputs(tag)
+    P = cga.Partition(sy["n"], sy["diag"], sy["upper"], sy["rows"], sy["cols"], nranks, rank)
+    D = cga.DistRank.from_partition(P)
+    nl = P.n_loc
+    b = cga.DeviceVector.from_host(sy["source"][P.lo:P.lo + nl]); x = cga.DeviceVector(nl)
+else:
+    nl = nx * ny * (nz * (rank + 1) // nranks - nz * rank // nranks)
+    b = cga.DeviceVector(nl); x = cga.DeviceVector(nl)
+    D = cga.DistRank.poisson(nx, ny, nz, points, 0x5EED0001, nranks, rank, b)
 desc = C.create_string_buffer(512)
 cga.check(L.cgh_dist_halo_descriptor(D.h, desc), "halo descriptor")
 publish("desc%d" % rank, desc.raw)
