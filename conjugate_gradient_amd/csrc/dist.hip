@@ -338,7 +338,7 @@ int finish_neighbours(cgh_dist *d)
 // ------------------------------------------------------------------------------------------ peer-to-peer halo
 // The same exchange without a library and without a launch of its own.  Every rank owns a deposit buffer (fine-grained
 // device memory shared through hipIpc): two slots, each an image of the halo tail of p with every entry as two tagged
-// 64-bit words (halo_ll.h).  The kernel that writes p (dist_update_xp) also stores the rows a neighbour needs into that
+// 64-bit words (halo_ll.h; per slot the low words of all entries, then the high words).  The kernel that writes p (dist_update_xp) also stores the rows a neighbour needs into that
 // neighbour's deposit, tagged with the NEXT iteration's exchange; the boundary-row SpMV of that iteration reads its halo
 // columns straight from its own deposit and waits, per entry, only if the tag is not there yet.  Two slots alternate: a
 // rank cannot push exchange k+2 before every neighbour has consumed exchange k (it needs their reduction messages of
@@ -443,11 +443,11 @@ int halo_connect(cgh_dist *d, const char *all)
             d->h_opened[i] = base;
         }
         halo_xfer &x = d->h_push[i];
-        x.dst = reinterpret_cast<uint64_t *>(base) + 2 * (size_t)h.e[at].recv_off;
+        x.dst = reinterpret_cast<uint64_t *>(base) + (size_t)h.e[at].recv_off;
         x.idx = nb.contig_start >= 0 ? nullptr : nb.d_send_idx;
         x.start = nb.contig_start >= 0 ? nb.contig_start : 0;
         x.cnt = nb.send_cnt;
-        x.slot_words = 2 * h.n_halo;
+        x.plane = h.n_halo;
         contiguous = contiguous && nb.contig_start >= 0;
     }
     d->d_push = (halo_xfer *)cgh_alloc(sizeof(halo_xfer) * (nnb ? nnb : 1));
@@ -476,6 +476,7 @@ cgh_ll_halo halo_view(const cgh_dist *d, int iter)
 {
     cgh_ll_halo h;
     h.dep = reinterpret_cast<const uint64_t *>(d->hbuf) + (size_t)(iter & 1) * 2 * (size_t)d->n_halo;
+    h.plane = d->n_halo;
     h.nl = d->n_loc;
     h.tag = cgh_ll_tag(d->epoch, (unsigned)iter);
     h.err = d->d_herr;
@@ -1014,7 +1015,8 @@ int cgh_dist_iterate(cgh_dist *d, int count, int time_kernels)
                 for (int j = 0; j < P.n; ++j) {
                     P.start[j] = d->h_push[j].start;
                     P.cnt[j] = d->h_push[j].cnt;
-                    P.dst[j] = d->h_push[j].dst + (size_t)((iter + 1) & 1) * (size_t)d->h_push[j].slot_words;
+                    P.dst[j] = d->h_push[j].dst + (size_t)((iter + 1) & 1) * 2 * (size_t)d->h_push[j].plane;
+                    P.plane[j] = d->h_push[j].plane;
                 }
                 d->pushed_iter = iter + 1;
             }

@@ -86,7 +86,23 @@ __device__ __forceinline__ void push_row(const cgh_pushes &P, int64_t row, doubl
 {
     for (int j = 0; j < P.n; ++j) {
         const int64_t k = row - P.start[j];
-        if (k >= 0 && k < P.cnt[j]) ll_store(P.dst[j] + 2 * k, v, P.tag);
+        if (k >= 0 && k < P.cnt[j]) ll_store(P.dst[j] + k, P.dst[j] + P.plane[j] + k, v, P.tag);
+    }
+}
+
+// rows row0, row0+1 of the new p
+__device__ __forceinline__ void push_pair(const cgh_pushes &P, int64_t row0, double v0, double v1)
+{
+    for (int j = 0; j < P.n; ++j) {
+        const int64_t k = row0 - P.start[j];
+        if (k < -1 || k >= P.cnt[j]) continue;
+        uint64_t *lo = P.dst[j] + k, *hi = lo + P.plane[j];
+        if (k >= 0 && k + 1 < P.cnt[j] && ((reinterpret_cast<uintptr_t>(lo) | reinterpret_cast<uintptr_t>(hi)) & 15u) == 0) {
+            ll_store_pair(lo, hi, v0, v1, P.tag);
+        } else {
+            if (k >= 0) ll_store(lo, hi, v0, P.tag);
+            if (k + 1 < P.cnt[j]) ll_store(lo + 1, hi + 1, v1, P.tag);
+        }
     }
 }
 
@@ -148,10 +164,7 @@ __global__ __launch_bounds__(CGH_BLOCK) void dist_update_xp(int64_t n, double *_
             st2<(VV & 2) != 0>(x, k, madd_rn(xv[j].x, alpha, pv[j].x), madd_rn(xv[j].y, alpha, pv[j].y));
             const double p0 = madd_rn(rv[j].x, beta, pv[j].x), p1 = madd_rn(rv[j].y, beta, pv[j].y);
             st2<false>(p, k, p0, p1);
-            if (P.n > 0) {
-                push_row(P, 2 * k, p0);
-                push_row(P, 2 * k + 1, p1);
-            }
+            if (P.n > 0) push_pair(P, 2 * k, p0, p1);
         }
     }
     for (int64_t cc = (int64_t)blockIdx.x + (int64_t)DIST_PRE * gridDim.x; cc < chunks; cc += gridDim.x) {
@@ -161,10 +174,7 @@ __global__ __launch_bounds__(CGH_BLOCK) void dist_update_xp(int64_t n, double *_
         st2<(VV & 2) != 0>(x, k, madd_rn(x2.x, alpha, p2.x), madd_rn(x2.y, alpha, p2.y));
         const double p0 = madd_rn(r2.x, beta, p2.x), p1 = madd_rn(r2.y, beta, p2.y);
         st2<false>(p, k, p0, p1);
-        if (P.n > 0) {
-            push_row(P, 2 * k, p0);
-            push_row(P, 2 * k + 1, p1);
-        }
+        if (P.n > 0) push_pair(P, 2 * k, p0, p1);
     }
     if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
         x[n - 1] = madd_rn(x[n - 1], alpha, p[n - 1]);
@@ -176,9 +186,10 @@ __global__ __launch_bounds__(CGH_BLOCK) void dist_update_xp(int64_t n, double *_
 
 // one neighbour's transfer as the stand-alone halo kernels see it
 struct halo_xfer {
-    uint64_t  *dst;      // push: the neighbour's deposit (slot 0) at my region, as mapped here
-    const int *idx;      // push: rows to send, NULL when they are contiguous from `start`
-    int64_t    start, cnt, slot_words;   // slot_words: 64-bit words between the two slots of that deposit
+    uint64_t  *dst;      // the neighbour's deposit (slot 0, low words) at my region, as mapped here
+    const int *idx;      // rows to send, NULL when they are contiguous from `start`
+    int64_t    start, cnt;
+    int64_t    plane;    // words from a slot's low words to its high words (= the neighbour's halo size); a slot is 2*plane
 };
 
 // grid: (workgroups per neighbour, neighbours)
@@ -187,9 +198,9 @@ __global__ __launch_bounds__(256) void halo_push_ll(const halo_xfer *__restrict_
 {
     if (done != nullptr && *done != 0) return;
     const halo_xfer a = xf[blockIdx.y];
-    uint64_t       *dst = a.dst + (size_t)slot * (size_t)a.slot_words;
+    uint64_t       *dst = a.dst + (size_t)slot * 2 * (size_t)a.plane;
     for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < a.cnt; k += (int64_t)gridDim.x * 256)
-        ll_store(dst + 2 * k, p[a.idx ? (int64_t)a.idx[k] : a.start + k], tag);
+        ll_store(dst + k, dst + a.plane + k, p[a.idx ? (int64_t)a.idx[k] : a.start + k], tag);
 }
 
 __global__ __launch_bounds__(256) void halo_pull_ll(cgh_ll_halo h, int64_t n_halo, double *__restrict__ halo_tail,

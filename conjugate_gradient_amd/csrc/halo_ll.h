@@ -11,7 +11,7 @@
 //                 sum (link_allreduce): workgroup 0 stores this rank's value into every peer's mailbox, every workgroup
 //                 polls its own mailbox for the peers' values and adds the N values in rank order (same bits everywhere)
 //   cgh_ll_halo   the deposit buffer a boundary SpMV reads halo entries of p from (ll_read), written by the neighbours'
-//                 p-update kernels (ll_store)
+//                 p-update kernels (ll_store_pair): per slot, the low words of all entries, then the high words
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -32,7 +32,8 @@ struct cgh_link {
 };
 
 struct cgh_ll_halo {
-    const uint64_t *dep;     // this exchange's slot of my deposit buffer: 2 words per halo entry, in halo order
+    const uint64_t *dep;     // this exchange's slot of my deposit buffer: the low words of all halo entries (halo order),
+    int64_t         plane;   // then, `plane` words further, their high words
     int64_t         nl;      // owned entries of p: column c >= nl is halo entry c - nl
     unsigned        tag;
     int            *err;
@@ -43,7 +44,8 @@ struct cgh_pushes {          // contiguous send ranges of p, pushed by the kerne
     int       n;
     unsigned  tag;
     int64_t   start[CGH_PUSH_MAX], cnt[CGH_PUSH_MAX];
-    uint64_t *dst[CGH_PUSH_MAX];   // the neighbour's deposit slot for this exchange, at my region, as mapped here
+    uint64_t *dst[CGH_PUSH_MAX];   // the neighbour's deposit slot for this exchange, at my region (low words), as mapped here
+    int64_t   plane[CGH_PUSH_MAX]; // words from there to the high words
 };
 
 // tag of exchange `idx` of solve `epoch`: never 0 (the value of a fresh buffer), low 2 bits = idx & 3
@@ -53,25 +55,43 @@ __host__ __device__ inline unsigned cgh_ll_tag(unsigned epoch, unsigned idx)
 }
 
 #ifdef __HIPCC__
-__device__ __forceinline__ void ll_store(uint64_t *dst, double v, unsigned tag)
+typedef unsigned long long cgh_ull2 __attribute__((ext_vector_type(2)));
+
+// One entry: low word to *lo, high word to *hi (system scope: written through, visible to a polling peer).
+__device__ __forceinline__ void ll_store(uint64_t *lo, uint64_t *hi, double v, unsigned tag)
 {
     const uint64_t bits = (uint64_t)__double_as_longlong(v), t = (uint64_t)tag << 32;
-    __hip_atomic_store(dst, t | (bits & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __hip_atomic_store(dst + 1, t | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(lo, t | (bits & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(hi, t | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-// Wait for the two words at q to carry `tag`; NaN (and *err = 1) after 10 s, or at once if an earlier wait timed out.
-__device__ __forceinline__ double ll_wait(const uint64_t *q, unsigned tag, int *err)
+// Two consecutive entries, lo and hi 16-byte aligned: two 16-byte stores with the cache bits of a system-scope store
+// (a volatile access compiles to `... sc0 sc1`), so that a wave writes whole, contiguous lines across xGMI.  Every
+// aligned 64-bit word still arrives whole, which is all the tags need.
+__device__ __forceinline__ void ll_store_pair(uint64_t *lo, uint64_t *hi, double v0, double v1, unsigned tag)
 {
-    uint64_t lo = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    uint64_t hi = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    const uint64_t b0 = (uint64_t)__double_as_longlong(v0), b1 = (uint64_t)__double_as_longlong(v1), t = (uint64_t)tag << 32;
+    cgh_ull2       l, h;
+    l.x = t | (b0 & 0xffffffffull);
+    l.y = t | (b1 & 0xffffffffull);
+    h.x = t | (b0 >> 32);
+    h.y = t | (b1 >> 32);
+    *reinterpret_cast<volatile cgh_ull2 *>(lo) = l;
+    *reinterpret_cast<volatile cgh_ull2 *>(hi) = h;
+}
+
+// Wait for the words at lo and hi to carry `tag`; NaN (and *err = 1) after 10 s, or at once if an earlier wait timed out.
+__device__ __forceinline__ double ll_wait(const uint64_t *lo_p, const uint64_t *hi_p, unsigned tag, int *err)
+{
+    uint64_t lo = __hip_atomic_load(lo_p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    uint64_t hi = __hip_atomic_load(hi_p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     if ((unsigned)(lo >> 32) != tag || (unsigned)(hi >> 32) != tag) {
         if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return __builtin_nan("");
         const long long t0 = wall_clock64();
         while (true) {
             __builtin_amdgcn_s_sleep(2);
-            lo = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            hi = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            lo = __hip_atomic_load(lo_p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            hi = __hip_atomic_load(hi_p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             if ((unsigned)(lo >> 32) == tag && (unsigned)(hi >> 32) == tag) break;
             if (wall_clock64() - t0 > CGH_LL_TIMEOUT_TICKS) {
                 atomicExch(err, 1);
@@ -82,7 +102,10 @@ __device__ __forceinline__ double ll_wait(const uint64_t *q, unsigned tag, int *
     return __longlong_as_double((long long)((hi << 32) | (lo & 0xffffffffull)));
 }
 
-__device__ __forceinline__ double ll_read(const cgh_ll_halo &h, int64_t entry) { return ll_wait(h.dep + 2 * entry, h.tag, h.err); }
+__device__ __forceinline__ double ll_read(const cgh_ll_halo &h, int64_t entry)
+{
+    return ll_wait(h.dep + entry, h.dep + h.plane + entry, h.tag, h.err);
+}
 
 // out[w] = sum over ranks (rank order) of mine[w], w < W <= 2.  Called by all 256 threads of every workgroup of the
 // launch with the same `mine`; `ex` holds 2*16 doubles of LDS.  Every thread returns the same bits on every rank.
@@ -98,8 +121,12 @@ __device__ __forceinline__ void link_allreduce(const cgh_link &L, const double *
             if (peer == L.me && !L.self) {
                 ex[t] = mine[w];
             } else {
-                if (blockIdx.x == 0) ll_store(L.peers[peer] + base + (size_t)L.me * CGH_LINK_WORDS + 2 * w, mine[w], L.tag);
-                ex[t] = ll_wait(L.box + base + (size_t)peer * CGH_LINK_WORDS + 2 * w, L.tag, L.err);
+                if (blockIdx.x == 0) {
+                    uint64_t *q = L.peers[peer] + base + (size_t)L.me * CGH_LINK_WORDS + 2 * w;
+                    ll_store(q, q + 1, mine[w], L.tag);
+                }
+                const uint64_t *q = L.box + base + (size_t)peer * CGH_LINK_WORDS + 2 * w;
+                ex[t] = ll_wait(q, q + 1, L.tag, L.err);
             }
         }
         __syncthreads();

@@ -241,7 +241,7 @@ inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 
 template <int DOT, int VAR, int DICT = 0, int HALO = 0>
 void launch_r2(int K, int grid, hipStream_t s, int64_t n, const double *diag, const double *vals, const void *cols,
                const int *off_tab, const double *x, double *y, double *partials, const int *done, int64_t rb, int64_t re,
-               int64_t rb2, int64_t re2, cgh_ll_halo hl = cgh_ll_halo{nullptr, 0, 0u, nullptr})
+               int64_t rb2, int64_t re2, cgh_ll_halo hl = cgh_ll_halo{nullptr, 0, 0, 0u, nullptr})
 {
 #define CGH_ELL_CASE(KK)                                                                                       \
     case KK:                                                                                                   \
