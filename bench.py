@@ -223,6 +223,15 @@ def main():
     cga.check(cga.lib().cgh_time_copy(dst.ptr, src.ptr, cbytes, 10, C.byref(ms)))
     out["roofline"]["copy_ceiling_GBs"] = 2 * cbytes / (ms.value * 1e-3) / 1e9
     out["roofline"]["frac_of_copy_ceiling"] = achieved / out["roofline"]["copy_ceiling_GBs"]
+    # ... and a read-only stream (the SpMV reads 12 bytes for every byte it writes): bytes read / time
+    sink = cga.DeviceVector(1024)
+    cga.check(cga.lib().cgh_time_read(src.ptr, sink.ptr, cbytes, 10, C.byref(ms)))
+    out["roofline"]["read_ceiling_GBs"] = cbytes / (ms.value * 1e-3) / 1e9
+    if out["roofline"]["traffic"]:
+        # what the SpMV really moves (PMC) over its measured time, against what a pure read stream reaches on this box
+        out["roofline"]["traffic_GBs"] = out["roofline"]["traffic"] / (spmv_ms * 1e-3) / 1e9
+        out["roofline"]["traffic_frac_of_read_ceiling"] = out["roofline"]["traffic_GBs"] / out["roofline"]["read_ceiling_GBs"]
+    del sink
     del src, dst
     # the same loop in the parity mode (strict=1: the reference's left-to-right dot / L1 order, bit-identical
     # trajectory, order-exact parallel sums of xsum.hip) -- reported beside the headline, never as `value`

@@ -137,6 +137,7 @@ def lib():
     L.cgh_dist_group_iterate.argtypes = [vpp, C.c_int, C.c_int]
     L.cgh_time_spmv.argtypes = [vp, vp, vp, C.c_int, dp]
     L.cgh_time_copy.argtypes = [vp, vp, C.c_size_t, C.c_int, dp]
+    L.cgh_time_read.argtypes = [vp, vp, C.c_size_t, C.c_int, dp]
     _lib = L
     return L
 
