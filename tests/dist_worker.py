@@ -3,7 +3,8 @@ of the test box, so the transport is the peer-to-peer one throughout (mailbox al
 and descriptors travel through files.
     python dist_worker.py <rank> <nranks> <dir> <nx> <ny> <nz> <points> <max_iter> <tol>     z-slabs from the device generator
     python dist_worker.py <rank> <nranks> <dir> tag <golden input> 0 0 <max_iter> <tol>      row blocks of a stored system
-Writes hist_<rank>.npy and x_<rank>.npy."""
+Writes hist_<rank>.npy and x_<rank>.npy.  A trailing "mute" makes rank 1 connect and then stay silent: rank 0's waits (halo
+entries in the SpMV, reduction messages in the vector kernels) must end after their limit and surface as an error."""
 import ctypes as C
 import os
 import sys
@@ -70,6 +71,40 @@ cga.check(L.cgh_dist_halo_connect(D.h, collect("desc", 512)), "halo connect")
 assert L.cgh_dist_halo_is_p2p(D.h) == 1
 publish("ready%d" % rank, b"1")          # barrier: every mailbox / deposit buffer is zeroed and mapped before anybody sends
 collect("ready", 1)
+
+if sys.argv[-1] == "mute":                   # two ranks
+    if rank == 1:
+        t0 = time.time()
+        while not os.path.exists(os.path.join(d, "finished0")):   # says nothing, pushes nothing; leaves after rank 0
+            assert time.time() - t0 < 150
+            time.sleep(0.05)
+        D.free()
+        L.cgh_p2p_disconnect()
+        print("rank 1 ok (mute)", flush=True)
+        sys.exit(0)
+    t0 = time.time()
+    D.start(b, x, tol, max_iter)             # (start's own reduction already waits for the silent peer)
+    failed = ""
+    try:
+        D.iterate(3, 0)
+        D.poll()
+    except RuntimeError as e:
+        failed = str(e)
+    hist = D.history(0, 4)
+    waited = time.time() - t0
+    assert failed and "did not arrive" in failed, failed
+    assert not np.all(np.isfinite(hist[1:, 0])), hist
+    assert 9.0 < waited < 60.0, waited       # each kind of wait gives up once, then nobody waits again
+    t1 = time.time()
+    D.iterate(3, 0)                          # later work does not wait at all
+    try:
+        D.poll()
+    except RuntimeError:
+        pass
+    assert time.time() - t1 < 5.0
+    publish("finished0", b"1")
+    print("rank 0 ok timeout after %.1f s: %s" % (waited, failed), flush=True)
+    sys.exit(0)
 
 D.start(b, x, tol, max_iter)
 done, queued = 0, 0

@@ -217,6 +217,30 @@ def test_multi_process_loop_from_partition(tmp_path, tag, G, env):
     _check_against_golden(hists[0].shape[0], hists[0], xs, g)
 
 
+def test_multi_process_loop_silent_neighbour(tmp_path):
+    """rank 1 connects and then says nothing: rank 0's waits inside the SpMV (halo entries) and inside the vector
+    kernels (reduction messages) end after their 10 s limit, the results are NaN, cgh_dist_poll reports it, and work
+    queued afterwards does not wait again"""
+    import os
+    import subprocess
+    import sys
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "dist_worker.py")
+    args = [str(v) for v in (32, 24, 20, 7, 40, 1e-9)] + ["mute"]
+    procs = [subprocess.Popen([sys.executable, worker, str(r), "2", str(tmp_path)] + args, stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=170)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append((p.returncode, out))
+    for r, (code, out) in enumerate(outs):
+        assert code == 0 and "rank %d ok" % r in out, out[-3000:]
+
+
 def test_multi_process_loop_larger_halo(tmp_path, cga):
     """4 processes on one GPU, 128x128x64 7-point (1M rows, halo planes of 16384 entries, 50 iterations): every rank's
     history identical, and equal to the single-GPU throughput-mode trajectory of the same matrix within rounding"""
