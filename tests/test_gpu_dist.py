@@ -185,7 +185,9 @@ def test_multi_process_loop_on_one_gpu(tmp_path, G, shape, points):
 @pytest.mark.parametrize("tag,G,env", [("cylinder_2000", 3, {}), ("cylinder_2000", 4, {"CGH_FUSED_PUSH": "0"}),
                                        ("cylinder_8000", 5, {}), ("poisson27_12x10x8", 4, {"CGH_DIST_LL_SPMV": "0"}),
                                        ("poisson27_12x10x8", 2, {"CGH_DIST_ONE_SPMV": "0"}),
-                                       ("poisson7_16", 4, {"CGH_FUSED_PUSH": "0", "CGH_DIST_ONE_SPMV": "0"})])
+                                       ("poisson7_16", 4, {"CGH_FUSED_PUSH": "0", "CGH_DIST_ONE_SPMV": "0"}),
+                                       ("poisson7_16", 2, {"CGH_LLC_MB": "0"}),          # the streaming (non-temporal) instantiations
+                                       ("poisson27_12x10x8", 3, {"CGH_LLC_MB": "0", "CGH_ELL_DICT": "0"})])
 def test_multi_process_loop_from_partition(tmp_path, tag, G, env):
     """The same between processes for ROW BLOCKS OF A STORED SYSTEM (cgh_dist_from_partition): send lists that are not
     contiguous (stand-alone push kernel with index lists), local sizes the vector SpMV cannot take (deposit unpacked
