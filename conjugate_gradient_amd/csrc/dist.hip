@@ -1017,7 +1017,10 @@ int cgh_dist_iterate(cgh_dist *d, int count, int time_kernels)
                     P.cnt[j] = d->h_push[j].cnt;
                     P.dst[j] = d->h_push[j].dst + (size_t)((iter + 1) & 1) * 2 * (size_t)d->h_push[j].plane;
                     P.plane[j] = d->h_push[j].plane;
+                    const int64_t chunk = (P.start[j] / 2) / CGH_BLOCK;
+                    if (chunk > P.rot) P.rot = chunk;  // start the sweep at the send range highest in memory
                 }
+                if (P.rot >= (nl / 2 + CGH_BLOCK - 1) / CGH_BLOCK) P.rot = 0;
                 d->pushed_iter = iter + 1;
             }
             if (cached)

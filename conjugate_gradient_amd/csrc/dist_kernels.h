@@ -115,11 +115,17 @@ __global__ __launch_bounds__(CGH_BLOCK) void dist_update_xp(int64_t n, double *_
     __shared__ double ex[2 * CGH_LINK_MAX_RANKS];
     const int64_t pairs = n >> 1;
     const int64_t chunks = (pairs + CGH_BLOCK - 1) / CGH_BLOCK;
+    // sweep position cc -> chunk: rotated so that the chunks at P.rot come first (see cgh_pushes)
+    auto chunk_of = [&](int64_t cc) {
+        const int64_t c = cc + P.rot;
+        return c >= chunks ? c - chunks : c;
+    };
     double2       xv[DIST_PRE], rv[DIST_PRE], pv[DIST_PRE];  // loads before the prologue, as in dist_update_r
 #pragma unroll
     for (int j = 0; j < DIST_PRE; ++j) {
-        const int64_t k = ((int64_t)blockIdx.x + (int64_t)j * gridDim.x) * CGH_BLOCK + threadIdx.x;
-        if (k < pairs) {
+        const int64_t cc = (int64_t)blockIdx.x + (int64_t)j * gridDim.x;
+        const int64_t k = chunk_of(cc) * CGH_BLOCK + threadIdx.x;
+        if (cc < chunks && k < pairs) {
             xv[j] = ld2<VV>(x, k);
             rv[j] = ld2<VV>(r, k);
             pv[j] = ld2<VV>(p, k);
@@ -158,8 +164,9 @@ __global__ __launch_bounds__(CGH_BLOCK) void dist_update_xp(int64_t n, double *_
     }
 #pragma unroll
     for (int j = 0; j < DIST_PRE; ++j) {
-        const int64_t k = ((int64_t)blockIdx.x + (int64_t)j * gridDim.x) * CGH_BLOCK + threadIdx.x;
-        if (k < pairs) {
+        const int64_t cc = (int64_t)blockIdx.x + (int64_t)j * gridDim.x;
+        const int64_t k = chunk_of(cc) * CGH_BLOCK + threadIdx.x;
+        if (cc < chunks && k < pairs) {
             // reference vec_axpy: out = a + alpha*b (vec.c:88-94): x += alpha p (cg.c:467), p = r + beta p (cg.c:489)
             st2<(VV & 2) != 0>(x, k, madd_rn(xv[j].x, alpha, pv[j].x), madd_rn(xv[j].y, alpha, pv[j].y));
             const double p0 = madd_rn(rv[j].x, beta, pv[j].x), p1 = madd_rn(rv[j].y, beta, pv[j].y);
@@ -168,7 +175,7 @@ __global__ __launch_bounds__(CGH_BLOCK) void dist_update_xp(int64_t n, double *_
         }
     }
     for (int64_t cc = (int64_t)blockIdx.x + (int64_t)DIST_PRE * gridDim.x; cc < chunks; cc += gridDim.x) {
-        const int64_t k = cc * CGH_BLOCK + threadIdx.x;
+        const int64_t k = chunk_of(cc) * CGH_BLOCK + threadIdx.x;
         if (k >= pairs) continue;
         const double2 x2 = ld2<VV>(x, k), r2 = ld2<VV>(r, k), p2 = ld2<VV>(p, k);
         st2<(VV & 2) != 0>(x, k, madd_rn(x2.x, alpha, p2.x), madd_rn(x2.y, alpha, p2.y));

@@ -43,6 +43,8 @@ constexpr int CGH_PUSH_MAX = 4;
 struct cgh_pushes {          // contiguous send ranges of p, pushed by the kernel that writes p
     int       n;
     unsigned  tag;
+    int64_t   rot;                 // the kernel starts its sweep at this 512-row chunk (and wraps): the send range highest in
+                                   // memory is then pushed in the first wave of workgroups too, not at the end of the kernel
     int64_t   start[CGH_PUSH_MAX], cnt[CGH_PUSH_MAX];
     uint64_t *dst[CGH_PUSH_MAX];   // the neighbour's deposit slot for this exchange, at my region (low words), as mapped here
     int64_t   plane[CGH_PUSH_MAX]; // words from there to the high words

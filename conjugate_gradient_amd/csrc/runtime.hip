@@ -29,6 +29,10 @@ int cgh_init(int device)
 {
     if (g_cgh.ready && g_cgh.device == device) return CGH_OK;
     if (g_cgh.ready) cgh_shutdown();
+    // The multi-rank transports share device memory between processes (hipIpc, RCCL); hosts whose driver only supports
+    // dmabuf IPC need this set BEFORE the runtime initialises (otherwise hipIpcGetMemHandle: invalid argument).  An
+    // explicit setting of the caller's is left alone.
+    setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0", 0);
     int count = 0;
     hipError_t e = hipGetDeviceCount(&count);
     if (e != hipSuccess || count == 0) {
