@@ -157,10 +157,12 @@ def main():
         raise SystemExit("WORLD_SIZE=%d does not match --gpus %d" % (world, args.gpus))
 
     nx, ny, nz, points = WORKLOADS[args.workload]
-    cga.init(local_rank)
+    # CGH_BENCH_SHARE_GPU=1: every rank on device 0 (the rehearsal of the launcher protocol on a one-GPU box)
+    cga.init(0 if os.environ.get("CGH_BENCH_SHARE_GPU") == "1" else local_rank)
 
     if world > 1 or args.dist:
-        cga.check(cga.lib().cgh_comm_preload(), "cgh_comm_preload")   # /opt/rocm's RCCL
+        if os.environ.get("CGH_BENCH_BOOTSTRAP") != "files":
+            cga.check(cga.lib().cgh_comm_preload(), "cgh_comm_preload")   # /opt/rocm's RCCL
         import bench_dist
         return bench_dist.run(args, rank, world, local_rank, (nx, ny, nz, points), SEED)
 

@@ -42,6 +42,49 @@ def exchange_unique_id(rank, world):
     raise SystemExit("bench_dist: rank %d never saw %s" % (rank, path))
 
 
+def connect_without_rccl(rank, world):
+    """CGH_BENCH_BOOTSTRAP=files: no RCCL at all -- the ranks hand their mailbox handles over through files and every
+    later exchange (barriers, max-over-ranks, halo descriptors) goes through the mailboxes.  This is how the launcher
+    protocol is rehearsed with several ranks on ONE GPU (tests/test_gpu_bench_launcher.py), which RCCL refuses."""
+    import ctypes as C
+    L = cga.lib()
+    prefix = "/tmp/cgh_boot_%d_%s_" % (os.getppid(), os.environ.get("MASTER_PORT", "0"))
+
+    def publish(name, data):
+        with open(prefix + name + ".tmp", "wb") as f:
+            f.write(data)
+        os.replace(prefix + name + ".tmp", prefix + name)
+
+    def collect(name, size):
+        out = []
+        for r in range(world):
+            deadline = time.time() + 300.0
+            while True:
+                try:
+                    with open(prefix + name + str(r), "rb") as f:
+                        data = f.read()
+                    if len(data) == size:
+                        break
+                except FileNotFoundError:
+                    pass
+                if time.time() > deadline:
+                    raise SystemExit("bench_dist: rank %d never saw %s%s%d" % (rank, prefix, name, r))
+                time.sleep(0.02)
+            out.append(data)
+        return b"".join(out)
+
+    buf = C.create_string_buffer(64)
+    cga.check(L.cgh_p2p_local_handle(buf), "cgh_p2p_local_handle")
+    publish("handle%d" % rank, buf.raw)
+    cga.check(L.cgh_p2p_connect(world, rank, collect("handle", 64)), "cgh_p2p_connect")
+    publish("ready%d" % rank, b"1")          # every mailbox is zeroed and mapped before anybody sends
+    collect("ready", 1)
+    cga.check(L.cgh_comm_init_local(world, rank), "cgh_comm_init_local")
+    barrier()
+    for name in ("handle%d" % rank, "ready%d" % rank):
+        os.unlink(prefix + name)
+
+
 def barrier():
     cga.comm_allreduce([0.0], "sum")
 
@@ -142,31 +185,35 @@ def measure(rank, world, shape, seed, steps, warmup, p2p_in_force):
 
 def run(args, rank, world, local_rank, shape, seed):
     nx, ny, nz, points = shape
-    ident, path = exchange_unique_id(rank, world)
-    # RCCL prints its version banner on stdout when the communicator comes up; stdout is for the one JSON line
-    sys.stdout.flush()
-    saved = os.dup(1)
-    os.dup2(2, 1)
-    try:
-        cga.comm_init(world, rank, ident)
-        barrier()
-    finally:
-        os.dup2(saved, 1)
-        os.close(saved)
-    if rank == 0:
-        os.unlink(path)
+    no_rccl = os.environ.get("CGH_BENCH_BOOTSTRAP") == "files"
+    if no_rccl:
+        connect_without_rccl(rank, world)
+    else:
+        ident, path = exchange_unique_id(rank, world)
+        # RCCL prints its version banner on stdout when the communicator comes up; stdout is for the one JSON line
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            cga.comm_init(world, rank, ident)
+            barrier()
+        finally:
+            os.dup2(saved, 1)
+            os.close(saved)
+        if rank == 0:
+            os.unlink(path)
 
-    path = validate_p2p(rank, world, seed)
-    p2p = path == "p2p"
+    path = "p2p (no RCCL in this run: CGH_BENCH_BOOTSTRAP=files)" if no_rccl else validate_p2p(rank, world, seed)
+    p2p = path.startswith("p2p")
     probe = None
-    if p2p:
+    if p2p and not no_rccl:
         p2p, probe = probe_transports(rank, world, shape, seed)
         if not p2p:
             path = "rccl (faster than p2p in the probe)"
     m = measure(rank, world, shape, seed, args.steps, args.warmup, p2p)
     if m is None:
         raise SystemExit("bench_dist: the workload could not be set up on every rank")
-    if not m["finite"] and p2p:
+    if not m["finite"] and p2p and not no_rccl:
         # the peer-to-peer reductions misbehaved under load after passing both checks: measure again over RCCL
         cga.lib().cgh_comm_set_p2p(0)
         p2p, path = False, "rccl (the run with p2p reductions produced non-finite residuals)"

@@ -413,6 +413,14 @@ int halo_connect(cgh_dist *d, const char *all)
 {
     if (!d->hbuf) return CGH_EINVAL;
     const size_t nnb = d->nbs.size();
+    // (a second connect -- by hand after the automatic one -- starts from a clean slate, keeping the deposit buffer)
+    for (void *p : d->h_opened)
+        if (p) (void)hipIpcCloseMemHandle(p);
+    cgh_free(d->d_push);
+    cgh_free(d->d_herr);
+    d->d_push = nullptr;
+    d->d_herr = nullptr;
+    d->halo_p2p = false;
     d->h_push.assign(nnb, halo_xfer{nullptr, nullptr, 0, 0, 0});
     d->h_opened.assign(nnb, nullptr);
     bool contiguous = true;
@@ -485,6 +493,31 @@ cgh_ll_halo halo_view(const cgh_dist *d, int iter)
 
 } // namespace
 
+// Ranks without RCCL (cgh_comm_init_local): every rank's `bytes` bytes (a multiple of 4), in rank order, through the
+// mailboxes.  A 32-bit word travels as an integer-valued double inside a sum whose other terms are zero, so the bits
+// arrive exactly.  Collective; slow (one exchange per two words and rank) but only used at set-up and by launchers.
+static int local_allgather(const void *mine, size_t bytes, void *all)
+{
+    const int N = g_rccl.nranks, me = g_rccl.rank;
+    if (bytes % 4 || !cgh_p2p_connected()) return CGH_EINVAL;
+    const size_t    words = bytes / 4;
+    const uint32_t *src = static_cast<const uint32_t *>(mine);
+    uint32_t       *dst = static_cast<uint32_t *>(all);
+    for (int r = 0; r < N; ++r)
+        for (size_t w = 0; w < words; w += 2) {
+            double v[2] = {0.0, 0.0};
+            if (r == me) {
+                v[0] = (double)src[w];
+                if (w + 1 < words) v[1] = (double)src[w + 1];
+            }
+            const int rc = cgh_p2p_allreduce_f64(v, 2);
+            if (rc) return rc;
+            dst[(size_t)r * words + w] = (uint32_t)v[0];
+            if (w + 1 < words) dst[(size_t)r * words + w + 1] = (uint32_t)v[1];
+        }
+    return CGH_OK;
+}
+
 // Peer-to-peer scalar all-reduce: all-gather the mailbox handles over the new communicator, connect, prove the path on
 // sums whose value is known, and let the ranks agree.  Any failure anywhere leaves the RCCL all-reduces in place.
 static bool setup_p2p(int nranks, int rank)
@@ -542,7 +575,20 @@ static bool setup_p2p(int nranks, int rank)
 static void auto_connect_halo(cgh_dist *d)
 {
     const char *env = getenv("CGH_P2P_HALO");
-    if (!g_rccl.comm || !g_rccl.p2p || (env && atoi(env) == 0) || g_rccl.nranks != d->nranks) return;
+    if (!g_rccl.p2p || (env && atoi(env) == 0) || g_rccl.nranks != d->nranks) return;
+    if (!g_rccl.comm) {
+        // ranks without RCCL: the descriptors travel through the mailboxes; a failure anywhere is everybody's failure
+        // (there is no other transport to fall back to: cgh_dist_start then refuses)
+        const size_t      n = (size_t)d->nranks;
+        std::vector<char> all(HALO_DESC_BYTES * n), mine(HALO_DESC_BYTES);
+        bool              ok = halo_descriptor(d, mine.data()) == CGH_OK;
+        if (!ok) memset(mine.data(), 0, mine.size());
+        ok = local_allgather(mine.data(), HALO_DESC_BYTES, all.data()) == CGH_OK && ok;
+        ok = ok && halo_connect(d, all.data()) == CGH_OK;
+        double v[2] = {ok ? 1.0 : 0.0, 0.0};
+        if (cgh_p2p_allreduce_f64(v, 1) != CGH_OK || v[0] != (double)d->nranks) halo_release(d);
+        return;
+    }
     hipStream_t       s = g_cgh.stream;
     const size_t      n = (size_t)d->nranks;
     std::vector<char> all(HALO_DESC_BYTES * n), mine(HALO_DESC_BYTES);
@@ -612,11 +658,27 @@ int cgh_comm_init(int nranks, int rank, const char id_bytes[256])
 int cgh_comm_allreduce_f64(double *h_vals, int count, int op)
 {
     CGH_REQUIRE_READY(CGH_ENODEV);
+    if (!h_vals || count < 1 || count > 64 || op < 0 || op > 2) return CGH_EINVAL;
+    if (!g_rccl.comm && g_rccl.p2p && cgh_p2p_connected()) {
+        // ranks without RCCL: gather everybody's values through the mailboxes, reduce here in rank order
+        const int           N = g_rccl.nranks;
+        std::vector<double> all((size_t)N * (size_t)count);
+        const int           rc = local_allgather(h_vals, sizeof(double) * (size_t)count, all.data());
+        if (rc) return rc;
+        for (int i = 0; i < count; ++i) {
+            double acc = all[i];
+            for (int r = 1; r < N; ++r) {
+                const double v = all[(size_t)r * count + i];
+                acc = op == 0 ? acc + v : (op == 1 ? (v > acc ? v : acc) : (v < acc ? v : acc));
+            }
+            h_vals[i] = acc;
+        }
+        return CGH_OK;
+    }
     if (!g_rccl.comm) {
         cgh_set_error("cgh_comm_allreduce_f64: no communicator (cgh_comm_init first)");
         return CGH_ECOMM;
     }
-    if (!h_vals || count < 1 || count > 64 || op < 0 || op > 2) return CGH_EINVAL;
     double *buf = (double *)cgh_alloc(sizeof(double) * 128);
     if (!buf) return CGH_ENOMEM;
     hipStream_t s = g_cgh.stream;

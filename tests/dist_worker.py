@@ -50,6 +50,8 @@ buf = C.create_string_buffer(64)
 cga.check(L.cgh_p2p_local_handle(buf), "local_handle")
 publish("handle%d" % rank, buf.raw)
 cga.check(L.cgh_p2p_connect(nranks, rank, collect("handle", 64)), "p2p connect")
+publish("connected%d" % rank, b"1")      # barrier: every mailbox is zeroed and mapped before anybody sends (creating
+collect("connected", 1)                  # a DistRank already does: it connects its halo through the mailboxes)
 cga.check(L.cgh_comm_init_local(nranks, rank), "comm_init_local")
 
 if tag:
@@ -64,7 +66,8 @@ else:
     nl = nx * ny * (nz * (rank + 1) // nranks - nz * rank // nranks)
     b = cga.DeviceVector(nl); x = cga.DeviceVector(nl)
     D = cga.DistRank.poisson(nx, ny, nz, points, 0x5EED0001, nranks, rank, b)
-desc = C.create_string_buffer(512)
+assert L.cgh_dist_halo_is_p2p(D.h) == 1          # connected by the constructor, through the mailboxes
+desc = C.create_string_buffer(512)               # ... and once more by hand, through files (the explicit API)
 cga.check(L.cgh_dist_halo_descriptor(D.h, desc), "halo descriptor")
 publish("desc%d" % rank, desc.raw)
 cga.check(L.cgh_dist_halo_connect(D.h, collect("desc", 512)), "halo connect")
