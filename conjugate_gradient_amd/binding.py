@@ -138,6 +138,8 @@ def lib():
     L.cgh_time_spmv.argtypes = [vp, vp, vp, C.c_int, dp]
     L.cgh_time_copy.argtypes = [vp, vp, C.c_size_t, C.c_int, dp]
     L.cgh_time_read.argtypes = [vp, vp, C.c_size_t, C.c_int, dp]
+    L.cgh_xsum_set_prof.argtypes = [vp]
+    L.cgh_xsum_set_prof.restype = None
     _lib = L
     return L
 

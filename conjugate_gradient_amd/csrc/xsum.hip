@@ -263,6 +263,14 @@ __global__ __launch_bounds__(256) void xs_summarize(int64_t n, const double *__r
 }
 
 // ---------------------------------------------------------------------------------------------- the driver
+// Optional profile of the serial walk (tools/prof_drive.py): lane 0 of the first wave in use adds event counts and
+// 100 MHz ticks into 16 words.  [0] batches of groups, [1] groups walked cell by cell, [2] cells added element by
+// element, [3] ticks in total, [4] ticks inside groups walked cell by cell, [5] ticks inside element chains (incl.
+// waiting for their elements), [6] launches.
+#define XS_PROF_ADD(k, v)                                                   \
+    do {                                                                    \
+        if (prof != nullptr && (threadIdx.x & 63) == 0) prof[k] += (v);     \
+    } while (0)
 __device__ __forceinline__ double readlane_f64(double v, int k)
 {
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), k), hi = __builtin_amdgcn_readlane(__double2hiint(v), k);
@@ -384,12 +392,14 @@ __device__ __forceinline__ void xs_prefetch_cells(xs_prefetch &f, int slot, int6
 template <int KIND>
 __device__ __forceinline__ double xs_walk_cells(double s, int slot, int64_t n, const double *__restrict__ a,
                                                 const double *__restrict__ b, const double *__restrict__ c, int64_t c0,
-                                                int ccnt, const xs_summary &C, double *stage, const xs_prefetch &f)
+                                                int ccnt, const xs_summary &C, double *stage, const xs_prefetch &f,
+                                                long long *prof = nullptr)
 {
     int cstart = 0;
     while (cstart < ccnt) {
         const int cf = xs_batch(C, cstart, ccnt, s);
         if (cf >= ccnt) break;
+        const long long tc0 = prof ? wall_clock64() : 0;
         double t0 = 0.0, t1 = 0.0;
         bool   have = false;
 #pragma unroll
@@ -401,6 +411,10 @@ __device__ __forceinline__ double xs_walk_cells(double s, int slot, int64_t n, c
             }
         if (!have) xs_cell_terms<KIND>(slot, n, a, b, c, c0 + cf, t0, t1);
         s = xs_chain(s, t0, t1, stage);
+        if (prof) {
+            XS_PROF_ADD(2, 1);
+            XS_PROF_ADD(5, wall_clock64() - tc0 + (long long)(s != s));  // (depends on s: the clock is read after the chain)
+        }
         cstart = cf + 1;
     }
     return s;
@@ -410,7 +424,8 @@ __device__ __forceinline__ double xs_walk_cells(double s, int slot, int64_t n, c
 // batch k is walked, its summaries and the elements of its flagged cells arrived while batch k-1 was walked.
 template <int KIND>
 __device__ double xs_walk_flat(int slot, int64_t n, const double *__restrict__ a, const double *__restrict__ b,
-                               const double *__restrict__ c, int64_t ncells, const xs_summary *__restrict__ cells, double *stage)
+                               const double *__restrict__ c, int64_t ncells, const xs_summary *__restrict__ cells, double *stage,
+                               long long *prof = nullptr)
 {
     const int lane = threadIdx.x & 63;
     cells += slot * ncells;
@@ -427,7 +442,8 @@ __device__ double xs_walk_flat(int slot, int64_t n, const double *__restrict__ a
     for (int64_t c0 = 0; c0 < ncells; c0 += 64) {
         const xs_summary C2 = load(c0 + 128);
         xs_prefetch_cells<KIND>(f1, slot, n, a, b, c, c0 + 64, count(c0 + 64), C1);
-        s = xs_walk_cells<KIND>(s, slot, n, a, b, c, c0, count(c0), C0, stage, f0);
+        XS_PROF_ADD(0, 1);
+        s = xs_walk_cells<KIND>(s, slot, n, a, b, c, c0, count(c0), C0, stage, f0, prof);
         C0 = C1;
         C1 = C2;
         f0 = f1;
@@ -438,47 +454,65 @@ __device__ double xs_walk_flat(int slot, int64_t n, const double *__restrict__ a
 template <int KIND>
 __device__ double xs_walk(int slot, int64_t n, const double *__restrict__ a, const double *__restrict__ b,
                           const double *__restrict__ c, int64_t ncells, int64_t ngroups, const xs_summary *__restrict__ cells,
-                          const xs_summary *__restrict__ groups, double *stage)
+                          const xs_summary *__restrict__ groups, double *stage, long long *prof = nullptr)
 {
     const int lane = threadIdx.x & 63;
     cells += slot * ncells;
     groups += slot * ngroups;
-    double     s = 0.0;
-    xs_summary Qnext = xs_identity();
-    if (lane < ngroups) Qnext = groups[lane];
+    double s = 0.0;
+    // group summaries: three batches ahead of the one being walked (a batch is ~0.5 us of work, a miss in L2 ~2 us)
+    auto load_groups = [&](int64_t g0) {
+        xs_summary q = xs_identity();
+        if (g0 + lane < ngroups) q = groups[g0 + lane];
+        return q;
+    };
+    xs_summary Q0 = load_groups(0), Q1 = load_groups(64), Q2 = load_groups(128);
     for (int64_t g0 = 0; g0 < ngroups; g0 += 64) {
         const int        cnt = (int)(ngroups - g0 < 64 ? ngroups - g0 : 64);
-        const xs_summary Q = Qnext;
-        Qnext = xs_identity();
-        if (g0 + 64 + lane < ngroups) Qnext = groups[g0 + 64 + lane];  // in flight while this batch is walked
-        // cell summaries of the first two groups already known to need their cells
-        unsigned long long flagged = __ballot(lane < cnt && (Q.meta & XS_IRREGULAR));
-        int                pf_g[2];
-        xs_summary         pf_C[2];
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            pf_g[j] = flagged ? (int)__builtin_ctzll(flagged) : -1;
-            flagged &= flagged - 1;
+        const xs_summary Q = Q0;
+        Q0 = Q1;
+        Q1 = Q2;
+        Q2 = load_groups(g0 + 192);
+        // Cell summaries of the groups already known to need their cells (irregular: a binade change is predicted inside,
+        // a tie, ...): two of them are always in flight ahead of the walk, refilled as the walk passes them.
+        unsigned long long remaining = __ballot(lane < cnt && (Q.meta & XS_IRREGULAR));
+        int                pf_g[2] = {-1, -1};
+        xs_summary         pf_C[2] = {xs_identity(), xs_identity()};
+        auto refill = [&](int j) {
+            pf_g[j] = remaining ? (int)__builtin_ctzll(remaining) : -1;
+            remaining &= remaining - 1;
             pf_C[j] = xs_identity();
             if (pf_g[j] >= 0 && (g0 + pf_g[j]) * XS_GROUP + lane < ncells) pf_C[j] = cells[(g0 + pf_g[j]) * XS_GROUP + lane];
-        }
+        };
+        refill(0);
+        refill(1);
+        XS_PROF_ADD(0, 1);
         int start = 0;
         while (start < cnt) {
             const int f = xs_batch(Q, start, cnt, s);
             if (f >= cnt) break;
+            const long long tg0 = prof ? wall_clock64() : 0;
             const int64_t c0 = (g0 + f) * XS_GROUP;
             const int     ccnt = (int)(ncells - c0 < XS_GROUP ? ncells - c0 : XS_GROUP);
             xs_summary    C = xs_identity();
-            if (f == pf_g[0]) {
-                C = pf_C[0];
-            } else if (f == pf_g[1]) {
-                C = pf_C[1];
-            } else if (lane < ccnt) {
-                C = cells[c0 + lane];
+            bool          have = false;
+            remaining &= f >= 63 ? 0ull : ~((2ull << f) - 1ull);  // nothing at or before f is worth fetching any more
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                if (pf_g[j] == f) {
+                    C = pf_C[j];
+                    have = true;
+                }
+                if (pf_g[j] >= 0 && pf_g[j] <= f) refill(j);  // used, or passed without being needed
             }
+            if (!have && lane < ccnt) C = cells[c0 + lane];
             xs_prefetch pf;
             xs_prefetch_cells<KIND>(pf, slot, n, a, b, c, c0, ccnt, C);
-            s = xs_walk_cells<KIND>(s, slot, n, a, b, c, c0, ccnt, C, stage, pf);
+            s = xs_walk_cells<KIND>(s, slot, n, a, b, c, c0, ccnt, C, stage, pf, prof);
+            if (prof) {
+                XS_PROF_ADD(1, 1);
+                XS_PROF_ADD(4, wall_clock64() - tg0 + (long long)(s != s));
+            }
             start = f + 1;
         }
     }
@@ -489,7 +523,8 @@ template <int KIND>
 __global__ __launch_bounds__(128) void xs_drive(int64_t n, const double *__restrict__ a, const double *__restrict__ b,
                                                const double *__restrict__ c, int64_t ncells, int64_t ngroups,
                                                const xs_summary *__restrict__ cells, const xs_summary *__restrict__ groups,
-                                               int mode, double *hist, int iter, double tol, int *done, double *out)
+                                               int mode, double *hist, int iter, double tol, int *done, double *out,
+                                               long long *prof_buf)
 {
     constexpr int S0 = KIND == XS_L1 ? 1 : 0, S1 = KIND == XS_DOT ? 0 : 1;
     __shared__ double res[2];
@@ -499,9 +534,15 @@ __global__ __launch_bounds__(128) void xs_drive(int64_t n, const double *__restr
     __syncthreads();
     const bool frozen = done != nullptr && mode != 3 && mode != 0 && *done != 0;
     if (!frozen && wave >= S0 && wave <= S1) {
-        const double s = groups != nullptr ? xs_walk<KIND>(wave, n, a, b, c, ncells, ngroups, cells, groups, stage[wave])
-                                           : xs_walk_flat<KIND>(wave, n, a, b, c, ncells, cells, stage[wave]);
+        long long      *prof = wave == S0 ? prof_buf : nullptr;
+        const long long t0 = prof ? wall_clock64() : 0;
+        const double s = groups != nullptr ? xs_walk<KIND>(wave, n, a, b, c, ncells, ngroups, cells, groups, stage[wave], prof)
+                                           : xs_walk_flat<KIND>(wave, n, a, b, c, ncells, cells, stage[wave], prof);
         if ((threadIdx.x & 63) == 0) res[wave] = s;
+        if (prof) {
+            XS_PROF_ADD(3, wall_clock64() - t0 + (long long)(s != s));
+            XS_PROF_ADD(6, 1);
+        }
     }
     __syncthreads();
     if (threadIdx.x != 0 || frozen) return;
@@ -527,6 +568,8 @@ __global__ __launch_bounds__(128) void xs_drive(int64_t n, const double *__restr
         hist[3] = NAN;
     }
 }
+
+long long *g_xs_prof = nullptr;  // device buffer of 16 words, or NULL (cgh_xsum_set_prof)
 
 template <int KIND>
 int launch_all(cgh_xsum *w, bool presummed, int64_t n, const double *a, const double *b, const double *c, int mode, double *hist, int iter,
@@ -556,7 +599,7 @@ int launch_all(cgh_xsum *w, bool presummed, int64_t n, const double *a, const do
     hipLaunchKernelGGL((xs_summarize<KIND>), dim3(flat ? 4 * ng : ng), dim3(256), 0, s, n, a, b, c, w->ncells, w->ngroups,
                        (const double *)w->cellsum, gsum, prefix, w->cells, grp);
     hipLaunchKernelGGL((xs_drive<KIND>), dim3(1), dim3(128), 0, s, n, a, b, c, w->ncells, w->ngroups,
-                       (const xs_summary *)w->cells, (const xs_summary *)grp, mode, hist, iter, tol, done, out);
+                       (const xs_summary *)w->cells, (const xs_summary *)grp, mode, hist, iter, tol, done, out, g_xs_prof);
     CGH_HIP(hipGetLastError());
     return CGH_OK;
 }
@@ -592,6 +635,9 @@ void cgh_xsum_free(cgh_xsum *w)
     cgh_free(w->groups);
     delete w;
 }
+
+// Profile of the serial walks that follow (see XS_PROF_ADD): 16 zeroed 64-bit words of device memory, or NULL to stop.
+extern "C" void cgh_xsum_set_prof(void *dev_16_words) { g_xs_prof = (long long *)dev_16_words; }
 
 double *cgh_xsum_cellsums(cgh_xsum *w) { return w ? w->cellsum : nullptr; }
 int64_t cgh_xsum_cells(const cgh_xsum *w) { return w ? w->ncells : 0; }

@@ -243,6 +243,8 @@ int     cgh_dist_loopback(cgh_dist *d);
 int cgh_time_spmv(const cgh_matrix *m, const double *d_x, double *d_y, int reps, double *ms_avg);
 /* float4-style device copy of `bytes` bytes, `reps` times: the attainable-HBM yardstick (ms per copy). */
 int cgh_time_copy(void *d_dst, const void *d_src, size_t bytes, int reps, double *ms_avg);
+/* profile of the serial walks of the order-exact sums (xsum.hip: XS_PROF_ADD): 16 zeroed 64-bit device words, or NULL */
+void cgh_xsum_set_prof(void *dev_16_words);
 /* read-only stream of `bytes` from d_src (d_sink_8k: 8 KiB of device scratch): the ceiling for read-dominated kernels */
 int cgh_time_read(const void *d_src, void *d_sink_8k, size_t bytes, int reps, double *ms_avg);
 
