@@ -19,6 +19,7 @@ points = int(sys.argv[1]) if len(sys.argv) > 1 else 7
 nx = ny = int(sys.argv[2]) if len(sys.argv) > 2 else 256
 nzl = int(sys.argv[3]) if len(sys.argv) > 3 else 32
 iters = 400
+tk = int(os.environ.get("TIME_KERNELS", "0"))   # 1: HIP events around every SpMV, as bench_dist's timed loop has them
 
 
 def timed(D, b, x):
@@ -28,7 +29,7 @@ def timed(D, b, x):
     best = 1e9
     for rep in range(2):
         t0 = time.perf_counter()
-        D.iterate(iters, 0)
+        D.iterate(iters, tk)
         cga.check(L.cgh_sync())
         best = min(best, (time.perf_counter() - t0) / iters * 1e6)
     h = D.history(0, 3 * iters + 1)
