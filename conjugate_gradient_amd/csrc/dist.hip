@@ -188,6 +188,15 @@ __global__ __launch_bounds__(256) void poisson_ell_slab(int nx, int ny, int nz, 
 
 inline int grid_for(int64_t work) { return cgh_stream_grid((work + 255) / 256, 8); }
 
+// stored entries whose column is a halo entry (id >= n_loc)
+__global__ __launch_bounds__(256) void count_halo_refs(int64_t total, const int *__restrict__ cols, int n_loc, unsigned long long *out)
+{
+    unsigned long long c = 0;
+    for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < total; k += (int64_t)gridDim.x * 256) c += cols[k] >= n_loc;
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, c);
+}
+
 } // namespace
 
 // ------------------------------------------------------------------------------------------ per-rank state
@@ -230,6 +239,7 @@ struct cgh_dist {
     unsigned epoch = 0;                            // number of this solve (same on every rank): part of every tag
     int      pushed_iter = 0;                      // the exchange dist_update_xp has already pushed
     bool     ll_spmv = false;                      // the boundary SpMV reads the deposit itself (vector path)
+    int64_t  halo_refs = -1;                       // stored entries with a halo column (counted at the first solve)
 };
 
 namespace {
@@ -968,11 +978,22 @@ int cgh_dist_start(cgh_dist *d, const double *d_b, double *d_x, double tol, int 
     CGH_HIP(hipMemsetAsync(d->p, 0, sizeof(double) * (size_t)(nl + d->n_halo), s));  // x0 = 0, halo of x0 = 0
     d->epoch = ++g_rccl.epoch;   // every rank starts its solves in the same order: the same number everywhere
     d->pushed_iter = 0;
-    d->ll_spmv = cgh_spmv_ell_halo_capable(&d->mat, d->p, d->Ap, 0, d->int_begin, d->int_end, nl);
-    {
-        const char *env = getenv("CGH_DIST_LL_SPMV");
-        if (env && atoi(env) == 0) d->ll_spmv = false;
+    // The SpMV reads halo entries straight from the deposit (uncached, tagged words) when each is wanted about once --
+    // the 7-point stencil.  With the 27-point stencil every halo entry is wanted by 9 rows: there one pass that unpacks
+    // the deposit into the halo tail of p, then cached gathers, is far cheaper (inner rank of 8 of 512^3, us per
+    // iteration: 1376 direct, 1069 unpacked, 1041 without neighbours).
+    if (d->halo_refs < 0 && d->n_halo > 0) {
+        unsigned long long *cnt = (unsigned long long *)cgh_alloc(sizeof(unsigned long long));
+        unsigned long long  h = 0;
+        if (!cnt || cgh_memset(cnt, 0, sizeof h) != CGH_OK) return CGH_ENOMEM;
+        hipLaunchKernelGGL(count_halo_refs, dim3(grid_for(d->mat.stored)), dim3(256), 0, s, d->mat.stored, (const int *)d->mat.cols, (int)nl, cnt);
+        rc = cgh_d2h(&h, cnt, sizeof h);
+        cgh_free(cnt);
+        if (rc) return rc;
+        d->halo_refs = (int64_t)h;
     }
+    d->ll_spmv = cgh_spmv_ell_halo_capable(&d->mat, d->p, d->Ap, 0, d->int_begin, d->int_end, nl) && d->halo_refs <= 2 * d->n_halo;
+    if (const char *env = getenv("CGH_DIST_LL_SPMV")) d->ll_spmv = atoi(env) != 0 && cgh_spmv_ell_halo_capable(&d->mat, d->p, d->Ap, 0, d->int_begin, d->int_end, nl);
     int cnt = 0;
     rc = spmv_ranges(d, true, true, false, &cnt, s, nullptr);  // Ap = A*0, as the reference computes it (cg.c:441)
     if (rc) return rc;

@@ -184,7 +184,8 @@ def test_multi_process_loop_on_one_gpu(tmp_path, G, shape, points):
 
 @pytest.mark.parametrize("tag,G,env", [("cylinder_2000", 3, {}), ("cylinder_2000", 4, {"CGH_FUSED_PUSH": "0"}),
                                        ("cylinder_8000", 5, {}), ("poisson27_12x10x8", 4, {"CGH_DIST_LL_SPMV": "0"}),
-                                       ("poisson27_12x10x8", 2, {"CGH_DIST_ONE_SPMV": "0"}),
+                                       ("poisson27_12x10x8", 2, {"CGH_DIST_LL_SPMV": "1", "CGH_DIST_ONE_SPMV": "0"}),
+                                       ("poisson27_12x10x8", 4, {"CGH_DIST_LL_SPMV": "1"}),   # 27-point: unpacked by default
                                        ("poisson7_16", 4, {"CGH_FUSED_PUSH": "0", "CGH_DIST_ONE_SPMV": "0"}),
                                        ("poisson7_16", 2, {"CGH_LLC_MB": "0"}),          # the streaming (non-temporal) instantiations
                                        ("poisson27_12x10x8", 3, {"CGH_LLC_MB": "0", "CGH_ELL_DICT": "0"})])
