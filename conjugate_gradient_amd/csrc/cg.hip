@@ -279,7 +279,8 @@ static int enqueue_iterations(cgh_solver *sv, int count, int time_kernels, bool 
         static const int serp = getenv("CGH_SERPENTINE") ? atoi(getenv("CGH_SERPENTINE")) : 0;
         const int        rev1 = serp ? (host_iter & 1) : 0, rev2 = serp ? !rev1 : 0;
         g_cgh.sweep_reverse = rev1;
-        if (time_kernels) {
+        const bool timed = time_kernels > 0 && c % time_kernels == 0;  // every time_kernels-th iteration of this call
+        if (timed) {
             hipEvent_t a, b;
             CGH_HIP(hipEventCreate(&a));
             CGH_HIP(hipEventCreate(&b));
@@ -296,7 +297,7 @@ static int enqueue_iterations(cgh_solver *sv, int count, int time_kernels, bool 
         g_cgh.cell_sums_written = false;
         if (rc) return rc;
         g_cgh.sweep_reverse = 0;
-        if (time_kernels) CGH_HIP(hipEventRecord(sv->kev.back(), s));
+        if (timed) CGH_HIP(hipEventRecord(sv->kev.back(), s));
         if (sv->precond == CGH_PRECOND_JACOBI) {
             const double *dg = sv->m->diag;
             hipLaunchKernelGGL(pcg_update_r, dim3(vg), dim3(CGH_BLOCK), 0, s, n, dr, (const double *)dAp, dg, (const double *)dA,

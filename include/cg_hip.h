@@ -119,7 +119,8 @@ typedef struct cgh_cg_opts {
     int    check_every;   /* iterations queued between host looks at the device's converged flag (>=1; 0 -> default 32).
                              The device freezes x at the converging iteration, so the result does not depend on this. */
     int    fixed_iters;   /* >0: run exactly this many iterations, never test convergence (benchmark mode) */
-    int    time_kernels;  /* 1: bracket the SpMV kernel of every iteration with HIP events (benchmark mode) */
+    int    time_kernels;  /* N > 0: bracket the SpMV kernel of every N-th iteration with HIP events (benchmark mode; two event
+                           * records cost ~6 us, which shows in iterations of a few tens of us) */
     int    precond;       /* CGH_PRECOND_NONE (0, the reference's loop) or CGH_PRECOND_JACOBI: z = r/diag, p = z + beta p,
                              alpha = r.z/(p.Ap); no reference counterpart, strict must be 0; history[.][1] = r.z */
 } cgh_cg_opts;
