@@ -117,8 +117,24 @@ while queued < max_iter - 1 and not done:
     if rank == nranks - 1:
         time.sleep(0.002)                  # skew: the last rank is always late
 iters = done if done else queued
-np.save(os.path.join(d, "hist_%d.npy" % rank), D.history(0, iters + 1))
+hist = D.history(0, iters + 1)
+np.save(os.path.join(d, "hist_%d.npy" % rank), hist)
 np.save(os.path.join(d, "x_%d.npy" % rank), x.to_host())
+# The same solve once more on the same object.  After convergence the ranks have queued different numbers of frozen
+# iterations (each stops at its own poll): the message tags count (solve, iteration), so the second solve must still
+# find every rank in step -- and give the same bits.
+x2 = cga.DeviceVector(nl)
+D.start(b, x2, tol, max_iter)
+done2, queued2 = 0, 0
+step = 5 + 3 * rank                        # ... and queue in different batch sizes this time
+while queued2 < max_iter - 1 and not done2:
+    D.iterate(min(step, max_iter - 1 - queued2), 0)
+    done2, queued2 = D.poll()
+iters2 = done2 if done2 else queued2
+assert iters2 == iters, (iters, iters2)
+hist2 = D.history(0, iters2 + 1)
+assert np.nan_to_num(hist2).tobytes() == np.nan_to_num(hist).tobytes()
+assert x2.to_host().tobytes() == x.to_host().tobytes()
 publish("finished%d" % rank, b"1")         # nobody unmaps a buffer a peer may still write to
 collect("finished", 1)
 D.free()
