@@ -240,14 +240,25 @@ __global__ __launch_bounds__(256) void xs_summarize(int64_t n, const double *__r
                 }
             }
             const unsigned long long bad_lanes = __ballot(bad);
+            // A cell of zeros only leaves any running sum as it is (s + (+-0) = s; the walk starts at +0 and never holds
+            // -0), whatever binade was predicted -- and none can be predicted while everything before it is zero too.
+            // CG on a right-hand side with small support (the OpenFOAM systems) keeps such prefixes for hundreds of
+            // iterations: without this every cell of them went element by element (foam-32k: 158 of 250 cells).
+            bool zeros = true;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) zeros = zeros && t[slot][k] == 0.0;
+            const unsigned long long zero_lanes = __ballot(zeros);
+            const bool               cell_is_zero = ((zero_lanes >> (lane & 48)) & 0xffffull) == 0xffffull;
             if (sub == 0) {
                 xs_summary q = xs_identity();
                 if (cell < ncells) {
-                    q.D = D;
-                    q.lo = lo;
-                    q.hi = hi;
-                    q.E = usable ? E : 0;
-                    q.meta = (neg ? 2 : 0) | (((bad_lanes >> (lane & 48)) & 0xffffull) ? XS_IRREGULAR : 0);
+                    if (!cell_is_zero) {
+                        q.D = D;
+                        q.lo = lo;
+                        q.hi = hi;
+                        q.E = usable ? E : 0;
+                        q.meta = (neg ? 2 : 0) | (((bad_lanes >> (lane & 48)) & 0xffffull) ? XS_IRREGULAR : 0);
+                    }
                     cells[slot * ncells + cell] = q;
                 }
                 sm[slot][ci] = q;

@@ -20,6 +20,9 @@ xs_summary summarize_cell(const double *t, int64_t cnt, double predicted_start)
 {
     xs_summary q = xs_identity();
     int32_t    E, neg;
+    bool       zeros = true;  // a cell of zeros only is the identity whatever the prediction (xsum.hip, xs_summarize)
+    for (int64_t k = 0; k < cnt; ++k) zeros = zeros && t[k] == 0.0;
+    if (zeros) return q;
     if (!xs_binade_of(predicted_start, &E, &neg)) {
         q.meta = XS_IRREGULAR;
         return q;

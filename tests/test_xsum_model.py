@@ -52,6 +52,12 @@ def cases():
     yield "zeros", np.zeros(5000)
     yield "zeros_then_data", np.concatenate([np.zeros(1000), rng.standard_normal(20000) ** 2])
     yield "data_then_zeros", np.concatenate([rng.standard_normal(20000) ** 2, np.zeros(30000)])
+    # all-zero cells are identity summaries (CG vectors of small support keep long zero prefixes)
+    yield "long_zero_prefix", np.concatenate([np.zeros(20000 + 37), rng.standard_normal(12000) ** 2])
+    yield "zero_holes", np.where((np.arange(n) // 1000) % 3 == 1, 0.0, rng.standard_normal(n))
+    yield "negative_zeros", np.concatenate([np.full(5000, -0.0), -(rng.standard_normal(3000) ** 2), np.full(7000, -0.0), rng.standard_normal(3000)])
+    yield "only_negative_zeros", np.full(4000, -0.0)
+    yield "zeros_cancel_zeros", np.concatenate([np.zeros(300), [1.5, -1.5], np.full(3000, -0.0), [2.0 ** -1060, -(2.0 ** -1060)], np.zeros(900), [7.0]])
     yield "subnormal", rng.standard_normal(40000) ** 2 * 5e-324 * 1000
     yield "tiny_and_huge", np.where(rng.random(n) < 0.001, 1e300, 1e-300) * rng.random(n)
     yield "ties", rng.integers(0, 8, n) * 0.5 + 2.0 ** 40 * (np.arange(n) == 0)      # every element is k/2 ulp-ish of the sum
