@@ -1,6 +1,9 @@
+"""Fixed cost of one call through the reference's host-pointer API (conjugate_gradient_ell_full_colmajor on the
+OpenFOAM cylinder_32k system): wall time for max_iter = 2, 34, 100, 1000.  CG_HIP_MODE=fast|strict selects the reductions."""
 import ctypes as C, os, sys, time
 import numpy as np
-sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 os.environ["CG_HIP_QUIET"] = "1"
 import conjugate_gradient_amd as cga, foamio, oracle_lib as O
 dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int)

@@ -1,6 +1,9 @@
+"""Strict (bit-identical) vs throughput iteration cost on the OpenFOAM systems the reference ships, with the profile of
+the serial walks of the order-exact sums (xsum.hip, XS_PROF_ADD)."""
 import os, sys
 import numpy as np
-sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import conjugate_gradient_amd as cga
 import foamio
 cga.init(0)

@@ -1,12 +1,20 @@
-import sys; sys.path.insert(0, ".")
-import ctypes as C, os
-import conjugate_gradient_amd as cga
+"""27-point 256^3 SpMV alone (no CG loop) under the env's kernel variants and layouts: ms and algorithmic TB/s."""
+import ctypes as C
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import conjugate_gradient_amd as cga  # noqa: E402
+
 cga.init(0)
-N = 256; n = N ** 3
+N = 256
+n = N ** 3
+layout = int(os.environ.get("LAYOUT", str(cga.LAYOUT_ELL)))
 b = cga.DeviceVector(n); y = cga.DeviceVector(n)
-A = cga.Matrix.poisson(N, N, N, 27, 0x5EED0001, 0, b)
+A = cga.Matrix.poisson(N, N, N, 27, 0x5EED0001, layout, b)
 alg = 12 * A.nnz_offdiag + 24 * n
 ms = C.c_double(); best = 1e9
 for _ in range(3):
     cga.check(cga.lib().cgh_time_spmv(A.h, b.ptr, y.ptr, 10, C.byref(ms))); best = min(best, ms.value)
-print("generic=%s variant=%s p27_256 spmv %.4f ms %.2f TB/s" % (os.environ.get("CGH_ELL_GENERIC"), os.environ.get("CGH_ELL_VARIANT"), best, alg / best / 1e9), flush=True)
+print("layout=%d generic=%s variant=%s dict=%s p27_256 spmv %.4f ms %.2f TB/s" % (layout, os.environ.get("CGH_ELL_GENERIC"),
+      os.environ.get("CGH_ELL_VARIANT"), os.environ.get("CGH_ELL_DICT"), best, alg / best / 1e9), flush=True)
