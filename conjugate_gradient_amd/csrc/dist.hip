@@ -985,7 +985,10 @@ int cgh_dist_start(cgh_dist *d, const double *d_b, double *d_x, double tol, int 
     if (d->halo_refs < 0 && d->n_halo > 0) {
         unsigned long long *cnt = (unsigned long long *)cgh_alloc(sizeof(unsigned long long));
         unsigned long long  h = 0;
-        if (!cnt || cgh_memset(cnt, 0, sizeof h) != CGH_OK) return CGH_ENOMEM;
+        if (!cnt || cgh_memset(cnt, 0, sizeof h) != CGH_OK) {
+            cgh_free(cnt);
+            return CGH_ENOMEM;
+        }
         hipLaunchKernelGGL(count_halo_refs, dim3(grid_for(d->mat.stored)), dim3(256), 0, s, d->mat.stored, (const int *)d->mat.cols, (int)nl, cnt);
         rc = cgh_d2h(&h, cnt, sizeof h);
         cgh_free(cnt);
