@@ -89,3 +89,35 @@ def test_config4_full_size_spmv_property(cga):
     twos = cga.DeviceVector.from_host(np.full(n, 2.0))
     A.spmv(twos, y)
     assert np.array_equal(bits(y.to_host()), bits(2.0 * want))
+
+
+def test_config5_full_size_properties(cga):
+    """BASELINE config 5 at its full size (8.4M rows, power-law row lengths 1..2000, ~75M off-diagonals): there is no
+    reference output at this size (its conversion alone would take minutes on the host), so size-independent checks:
+    (1) the CSR stream/adaptive and the sliced-ELL kernels, with the reference's per-row order forced for long rows too,
+        give bit-identical y; (2) A*1 = 1 up to the rounding of one row (diag = 1 + sum|a_ij|, a_ij <= 0);
+    (3) symmetry: z.(A x) = x.(A z) to rounding."""
+    n, max_len, seed = 8 * 1024 * 1024, 2000, 0x5EED0005
+    rng = np.random.default_rng(5)
+    xh, zh = rng.standard_normal(n), rng.standard_normal(n)
+    x, z, ones = cga.DeviceVector.from_host(xh), cga.DeviceVector.from_host(zh), cga.DeviceVector.from_host(np.ones(n))
+    ys = {}
+    for layout in (cga.LAYOUT_CSR, cga.LAYOUT_SELL):
+        b = cga.DeviceVector(n)
+        A = cga.Matrix.powerlaw(n, max_len, seed, layout, b)
+        A.set_exact_rows(True)
+        assert A.n == n and 1000 < A.K <= max_len + 48 and A.nnz_offdiag > 7 * n
+        y = cga.DeviceVector(n)
+        A.spmv(x, y); yx = y.to_host()
+        A.spmv(ones, y); y1 = y.to_host()
+        if layout == cga.LAYOUT_CSR:
+            A.spmv(z, y); yz = y.to_host()
+            diag = A.download_diag()
+            assert np.all(diag >= 1.0)
+            assert np.max(np.abs(y1 - 1.0) / diag) < 1e-12                 # (2)
+            lhs, rhs = float(zh @ yx), float(xh @ yz)
+            assert abs(lhs - rhs) <= 1e-10 * (np.abs(zh) @ np.abs(yx))      # (3)
+        ys[layout] = (yx, y1)
+        A.free()
+    assert np.array_equal(bits(ys[cga.LAYOUT_CSR][0]), bits(ys[cga.LAYOUT_SELL][0]))   # (1)
+    assert np.array_equal(bits(ys[cga.LAYOUT_CSR][1]), bits(ys[cga.LAYOUT_SELL][1]))
