@@ -99,6 +99,35 @@ def cpu_baseline(A, b_dev, budget_s=15.0):
                       "its SpMV alone: %.3f s = %.2f GB/s algorithmic" % (iters, n, dt, t_spmv, alg / t_spmv / 1e9)}
 
 
+def cpu_all_cores(A, b_dev, iters=40):
+    """The same loop with OpenMP row-parallel sweeps on the host cores this process may use (oracle/cg_omp.c): NOT the
+    reference's execution model (it is single-threaded) and not bit-identical to it -- reported beside `cpu_baseline` so
+    that the GPU figure can also be read against a whole host."""
+    so = os.path.join(ROOT, "oracle", "libcg_omp.so")
+    if not os.path.exists(so):
+        return None
+    try:
+        L = C.CDLL(so)
+    except OSError:
+        return None
+    n, K = A.n, A.K
+    ev, ec = A.download_ell()
+    diag = A.download_diag()
+    b = b_dev.to_host()
+    x = np.zeros(n)
+    dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int)
+    L.orc_cg_ell_full_omp.argtypes = [C.c_int, dp, dp, ip, C.c_int, dp, dp, C.c_int, C.c_double]
+    args = (n, diag.ctypes.data_as(dp), ev.ctypes.data_as(dp), ec.ctypes.data_as(ip), K, b.ctypes.data_as(dp), x.ctypes.data_as(dp))
+    L.orc_cg_ell_full_omp(*args, 3, -1.0)                    # first touch, thread pool
+    t0 = time.perf_counter()
+    L.orc_cg_ell_full_omp(*args, iters + 1, -1.0)
+    dt = time.perf_counter() - t0
+    threads = int(L.orc_omp_threads())
+    return {"value": iters / dt, "unit": "iterations/s", "cores": threads, "kind": "port (OpenMP row-parallel sweeps; not the reference's "
+            "single-threaded execution model, not bit-identical)", "sample": "%d CG iterations of the same %d-row matrix, %d threads, %.1f s"
+            % (iters, n, threads, dt)}
+
+
 def rehearse_inner_rank(nx, ny, nz, points, ranks, one_gpu_rate):
     """What ONE GPU can say about the N-GPU run: the z-slab of an inner rank (rank 3 of 8) of the same matrix, with this
     GPU as both of its neighbours (cgh_dist_loopback: deposits, tags, mailbox all-reduces and waits as between GPUs, the
@@ -255,6 +284,9 @@ def main():
         out["multi_gpu_rehearsal"]["of_4"] = rehearse_inner_rank(nx, ny, nz, points, 4, args.steps / dt)
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(A, b)
+        allc = cpu_all_cores(A, b)
+        if allc:
+            out["cpu_baseline_all_cores"] = allc
     print(json.dumps(out), flush=True)
 
 

@@ -172,3 +172,28 @@ def test_foam2000_matches_reference_log():
     assert int(g["cg_ret"][4]) == 254
     assert abs(O.lib().orc_rmse(O.D(x), O.D(phi), 2000) - 0.003061) < 5e-7
     assert abs(O.lib().orc_max_difference(O.D(x), O.D(phi), 2000) - 0.004555) < 5e-7
+
+
+def test_openmp_variant_agrees_with_the_oracle_to_rounding():
+    """oracle/cg_omp.c (bench.py's all-core CPU figure) runs the same loop with OpenMP reductions: same iteration count
+    and solution as the order-exact oracle within rounding on a golden system"""
+    import ctypes as C
+    import os
+    so = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "oracle", "libcg_omp.so")
+    if not os.path.exists(so):
+        pytest.skip("oracle/libcg_omp.so not built (run `make -C oracle`)")
+    L = C.CDLL(so)
+    s = foamio.poisson_coo(16, 16, 16, 0x5EED0001, 7)
+    n = s["n"]
+    K = O.max_nnz_full(n, s["rows"], s["cols"])
+    ev, ec, st = O.coo_to_ell_full(n, s["upper"], s["rows"], s["cols"], K)
+    ret, xo, traj = O.cg(O.FMT_ELL_FULL, n, s["diag"], 0, ev, ec, None, K, s["source"], 500, 1e-8)
+    dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int)
+    L.orc_cg_ell_full_omp.argtypes = [C.c_int, dp, dp, ip, C.c_int, dp, dp, C.c_int, C.c_double]
+    x = np.zeros(n)
+    diag = np.ascontiguousarray(s["diag"]); b = np.ascontiguousarray(s["source"])
+    got = L.orc_cg_ell_full_omp(n, diag.ctypes.data_as(dp), ev.ctypes.data_as(dp), ec.ctypes.data_as(ip), K, b.ctypes.data_as(dp),
+                                x.ctypes.data_as(dp), 500, 1e-8)
+    assert ret > 0 and abs(got - ret) <= 1
+    assert np.max(np.abs(x - xo)) <= 1e-9 * max(1.0, np.max(np.abs(xo)))
+    assert L.orc_omp_threads() >= 1
