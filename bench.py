@@ -216,7 +216,7 @@ def main():
     achieved = alg_spmv / (spmv_ms * 1e-3) / 1e9
     ms_step = dt / args.steps * 1e3
     out = {
-        "metric": "CG iterations/sec (SpMV achieved HBM GB/s in roofline)",
+        "metric": "CG iters/sec + SpMV achieved HBM GB/s (% of peak): value = CG iterations/s, the SpMV figures are in roofline",
         "value": args.steps / dt,
         "unit": "iterations/s",
         "n_gpus": 1,

@@ -232,7 +232,7 @@ def run(args, rank, world, local_rank, shape, seed):
         extra = measure(rank, world, (512, 512, 512, 27), seed, min(args.steps, 20), min(args.warmup, 3), p2p)
     if rank == 0:
         out = {
-            "metric": "CG iterations/sec (SpMV achieved HBM GB/s in roofline)",
+            "metric": "CG iters/sec + SpMV achieved HBM GB/s (% of peak): value = CG iterations/s, the SpMV figures are in roofline",
             "value": args.steps / m["dt"], "unit": "iterations/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": m["ms_step"], "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
