@@ -36,13 +36,18 @@ import conjugate_gradient_amd as cga  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
 
 WORKLOADS = {
-    # name: (nx, ny, nz, points)
-    "p7_256": (256, 256, 256, 7),
+    # name: (nx, ny, nz, points) -- seeded Poisson stencils, slot-major ELL
+    "p7_256": (256, 256, 256, 7),            # BASELINE configs[2]: the headline
     "p7_128": (128, 128, 128, 7),
     "p27_256": (256, 256, 256, 27),
-    "p27_512": (512, 512, 512, 27),
+    "p27_512": (512, 512, 512, 27),          # configs[3]'s matrix on ONE GPU
+    "foam_standin_128k": (400, 320, 1, 7),   # configs[0-1]: size stand-in for the missing foam_128k blob (2-D 5-point, K = 4)
+    # name: ("powerlaw", rows, max row length) -- configs[4]: column-blocked CSR (CSR-adaptive, sliced ELL beside it)
+    "pl_8m": ("powerlaw", 8 * 1024 * 1024, 2000),
+    "pl_1m": ("powerlaw", 1024 * 1024, 2000),
 }
 SEED = 0x5EED0001
+PL_SEED = 0x5EED0005
 
 
 class quiet_stdout:
@@ -97,6 +102,52 @@ def cpu_baseline(A, b_dev, budget_s=15.0):
     return {"value": iters / dt, "unit": "iterations/s", "cores": 1, "kind": kind,
             "sample": "%d CG iterations of the same %d-row matrix (plus the set-up SpMV), 1 thread, %.1f s; "
                       "its SpMV alone: %.3f s = %.2f GB/s algorithmic" % (iters, n, dt, t_spmv, alg / t_spmv / 1e9)}
+
+
+def cpu_baseline_csr(A_csr, b_dev, budget_s=15.0):
+    """Config 5: the reference's own CSR path on one host core -- mv_csr_symmetric (src/csr.c:190-229) and
+    conjugate_gradient_csr (src/cg.c:121-222) on the strictly-upper CSR of the same matrix (the upper entries of the
+    device's full rows, which keep the generation order the reference's conversion would see)."""
+    n = A_csr.n
+    rp, cols, vals = A_csr.download_csr()
+    diag = A_csr.download_diag()
+    rows = np.repeat(np.arange(n, dtype=np.int32), np.diff(rp).astype(np.int64))
+    up = cols > rows
+    ucols = np.ascontiguousarray(cols[up]); uvals = np.ascontiguousarray(vals[up])
+    urp = np.zeros(n + 1, dtype=np.int32)
+    np.cumsum(np.bincount(rows[up], minlength=n), out=urp[1:])
+    del rows, up, cols, vals, rp
+    U = int(ucols.size)
+    b = b_dev.to_host()
+    x = np.zeros(n)
+    dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int)
+    D = lambda a: a.ctypes.data_as(dp)  # noqa: E731
+    I = lambda a: a.ctypes.data_as(ip)  # noqa: E731
+    ref_so = os.path.join(ROOT, "oracle", "_ref", "libref.so")
+    if os.path.exists(ref_so):
+        kind = "reference"
+        L = C.CDLL(ref_so)
+        spmv = lambda: L.mv_csr_symmetric(n, D(diag), D(uvals), I(ucols), I(urp), D(b), D(x))  # noqa: E731
+        L.conjugate_gradient_csr.argtypes = [C.c_int, dp, C.c_int, dp, ip, ip, dp, dp, C.c_int, C.c_double]
+        solve = lambda mi: L.conjugate_gradient_csr(n, D(diag), U, D(uvals), I(urp), I(ucols), D(b), D(x), mi, -1.0)  # noqa: E731
+    else:
+        import oracle_lib as O
+        kind = "port"
+        L = O.lib()
+        spmv = lambda: L.orc_mv_csr_symmetric(n, D(diag), D(uvals), I(ucols), I(urp), D(b), D(x))  # noqa: E731
+        solve = lambda mi: L.orc_cg(O.FMT_CSR, n, D(diag), U, D(uvals), I(urp), I(ucols), 0, D(b), D(x), mi, -1.0, None)  # noqa: E731
+    t0 = time.perf_counter()
+    spmv()
+    t_spmv = time.perf_counter() - t0
+    iters = int(max(3, min(60, budget_s / (2.0 * t_spmv))))
+    with quiet_stdout():
+        t0 = time.perf_counter()
+        solve(iters + 1)
+        dt = time.perf_counter() - t0
+    alg = 12 * 2 * U + 24 * n
+    return {"value": iters / dt, "unit": "iterations/s", "cores": 1, "kind": kind,
+            "sample": "%d iterations of conjugate_gradient_csr on the strictly-upper CSR of the same %d-row matrix (plus the set-up "
+                      "SpMV), 1 thread, %.1f s; its mv_csr_symmetric alone: %.3f s = %.2f GB/s algorithmic" % (iters, n, dt, t_spmv, alg / t_spmv / 1e9)}
 
 
 def cpu_all_cores(A, b_dev, iters=40):
@@ -186,20 +237,27 @@ def main():
                              % (args.gpus, args.gpus))
         raise SystemExit("WORLD_SIZE=%d does not match --gpus %d" % (world, args.gpus))
 
-    nx, ny, nz, points = WORKLOADS[args.workload]
+    wl = WORKLOADS[args.workload]
+    powerlaw = wl[0] == "powerlaw"
+    nx, ny, nz, points = (0, 0, 0, 0) if powerlaw else wl
     # CGH_BENCH_SHARE_GPU=1: every rank on device 0 (the rehearsal of the launcher protocol on a one-GPU box)
     cga.init(0 if os.environ.get("CGH_BENCH_SHARE_GPU") == "1" else local_rank)
 
     if world > 1 or args.dist:
+        if powerlaw:
+            raise SystemExit("the power-law workload is a one-GPU workload (BASELINE configs[4])")
         if os.environ.get("CGH_BENCH_BOOTSTRAP") != "files":
             cga.check(cga.lib().cgh_comm_preload(), "cgh_comm_preload")   # /opt/rocm's RCCL
         import bench_dist
         return bench_dist.run(args, rank, world, local_rank, (nx, ny, nz, points), SEED)
 
-    n = nx * ny * nz
+    n = wl[1] if powerlaw else nx * ny * nz
     b = cga.DeviceVector(n)
     x = cga.DeviceVector(n)
-    A = cga.Matrix.poisson(nx, ny, nz, points, SEED, cga.LAYOUT_ELL, b)
+    if powerlaw:
+        A = cga.Matrix.powerlaw(n, wl[2], PL_SEED, cga.LAYOUT_CSRB, b)
+    else:
+        A = cga.Matrix.poisson(nx, ny, nz, points, SEED, cga.LAYOUT_ELL, b)
     sv = cga.Solver(A, args.warmup + args.steps + 1)
     sv.start(b, x, tol=-1.0, strict=0)          # tol < 0: never converges, every step does full work
     sv.iterate(args.warmup, 0)
@@ -215,6 +273,15 @@ def main():
     alg_spmv = 12 * A.nnz_offdiag + 24 * n       # 12*nnz_off + 24*n per SpMV
     achieved = alg_spmv / (spmv_ms * 1e-3) / 1e9
     ms_step = dt / args.steps * 1e3
+    if powerlaw:
+        what = ("%s: SPD matrix with power-law row lengths (Pareto exponent 2, 1..%d entries per row, realised max %d, mean %.2f), "
+                "columns uniformly random, %d rows, column-blocked CSR, unpreconditioned CG" % (args.workload, wl[2], A.K, A.nnz_offdiag / n, n))
+        kernel = ("spmv_csrb (column-blocked CSR SpMV + p.Ap partials: 12 bytes per entry, row sums in LDS, gathers of x paced "
+                  "slab by slab through L2; HIP events around every 4th launch of the timed region)")
+    else:
+        what = "%s: 3-D %d-point Poisson %dx%dx%d, %d rows, slot-major ELL K=%d, unpreconditioned CG" % (args.workload, points, nx, ny, nz, n, A.K)
+        kernel = "spmv_ell_r2 (SpMV + p.Ap partials; %s; HIP events around every 4th launch of the timed region)" % (
+            "1-byte dictionary-coded columns, %d offsets" % A.dict_offsets if A.dict_offsets > 0 else "int32 columns")
     out = {
         "metric": "CG iters/sec + SpMV achieved HBM GB/s (% of peak): value = CG iterations/s, the SpMV figures are in roofline",
         "value": args.steps / dt,
@@ -228,24 +295,25 @@ def main():
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic",
-        "config": {"workload": "%s: 3-D %d-point Poisson %dx%dx%d, %d rows, slot-major ELL K=%d, unpreconditioned CG"
-                               % (args.workload, points, nx, ny, nz, n, A.K),
+        "config": {"workload": what,
                    "rows": n, "nnz_offdiag": int(A.nnz_offdiag), "parallelism": "1 GPU",
                    "iter_bytes_algorithmic": int(12 * A.nnz_offdiag + 96 * n),
                    "iter_GBs_algorithmic": (12 * A.nnz_offdiag + 96 * n) / (ms_step * 1e-3) / 1e9,
                    "residual_l1_half_first_last": [float(hist[0, 0]), float(hist[-1, 0])]},
-        "roofline": {"bound": "hbm", "kernel": "spmv_ell_r2 (SpMV + p.Ap partials; %s; HIP events around every 4th launch of the timed region)"
-                     % ("1-byte dictionary-coded columns, %d offsets" % A.dict_offsets if A.dict_offsets > 0 else "int32 columns"),
+        "roofline": {"bound": "hbm", "kernel": kernel,
                      "achieved": achieved,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "bytes_per_launch": int(alg_spmv), "ms_per_launch": spmv_ms, "traffic": None},
     }
     # HBM traffic of the SpMV from the PMC counters: collected in separate rocprofv3 passes (it cannot be read live) and
     # committed under profiles/ with its derivation; reported only for the workload it was measured on
-    tpath = os.path.join(ROOT, "profiles", "r01_traffic_%s.json" % args.workload)
-    if os.path.exists(tpath):
-        with open(tpath) as f:
-            out["roofline"]["traffic"] = json.load(f)["hbm_bytes_per_launch"]
+    for rnd in ("r02", "r01"):
+        tpath = os.path.join(ROOT, "profiles", "%s_traffic_%s.json" % (rnd, args.workload))
+        if os.path.exists(tpath):
+            with open(tpath) as f:
+                out["roofline"]["traffic"] = json.load(f)["hbm_bytes_per_launch"]
+            out["roofline"]["traffic_source"] = "profiles/" + os.path.basename(tpath)
+            break
     sv.free()
     # attainable ceiling next to the spec peak: device-to-device copy kernel, 1 GiB, bytes read + written
     cbytes = 1 << 30                                 # far beyond the 256 MiB Infinity Cache
@@ -265,6 +333,33 @@ def main():
         out["roofline"]["traffic_frac_of_read_ceiling"] = out["roofline"]["traffic_GBs"] / out["roofline"]["read_ceiling_GBs"]
     del sink
     del src, dst
+    if powerlaw:
+        # the other layouts of config 5 beside the headline: CSR stream/adaptive (the parity-capable one, also what the CPU
+        # baseline reads back), sliced ELL plain and sigma-sorted; the reference's single-width ELL is only priced
+        Kfull = A.K
+        sv.free()
+        A.free()
+        ms = C.c_double(0.0)
+        y = cga.DeviceVector(n)
+        lay = {}
+        csr_bytes = None
+        for name, layout in (("csr_stream_adaptive", cga.LAYOUT_CSR), ("sliced_ell_sigma_sorted", cga.LAYOUT_SELLS), ("sliced_ell_64", cga.LAYOUT_SELL)):
+            M = cga.Matrix.powerlaw(n, wl[2], PL_SEED, layout, b)
+            cga.check(cga.lib().cgh_time_spmv(M.h, b.ptr, y.ptr, 10, C.byref(ms)))
+            if layout == cga.LAYOUT_CSR:
+                csr_bytes = M.stored_bytes
+            lay[name] = {"stored_bytes": int(M.stored_bytes), "bytes_vs_csr": M.stored_bytes / csr_bytes, "spmv_ms": ms.value,
+                         "spmv_GBs_algorithmic": alg_spmv / ms.value / 1e6, "frac": alg_spmv / ms.value / 1e6 / HBM_PEAK_GBS}
+            if layout == cga.LAYOUT_CSR and not args.no_cpu_baseline:
+                out["cpu_baseline"] = cpu_baseline_csr(M, b)
+            M.free()
+        lay["column_blocked_csr"] = {"spmv_ms": spmv_ms, "spmv_GBs_algorithmic": achieved, "frac": achieved / HBM_PEAK_GBS,
+                                     "note": "the headline kernel; 12 bytes per entry + slab offsets, parity by tolerance (fixed order, not the reference's)"}
+        out["config"]["layouts"] = lay
+        lay["ell_single_width"] = {"stored_bytes": int(n * Kfull * 12 + n * 8), "bytes_vs_csr": (n * Kfull * 12 + n * 8) / csr_bytes,
+                                   "note": "not instantiated: what the reference's one-width ELL (src/ell.c:791-858) would store at K = %d" % Kfull}
+        print(json.dumps(out), flush=True)
+        return
     # the same loop in the parity mode (strict=1: the reference's left-to-right dot / L1 order, bit-identical
     # trajectory, order-exact parallel sums of xsum.hip) -- reported beside the headline, never as `value`
     ps = min(args.steps, 50)
@@ -273,12 +368,16 @@ def main():
     sv.iterate(2, 0)
     cga.check(cga.lib().cgh_sync())
     t0 = time.perf_counter()
-    sv.iterate(ps, 0)
+    sv.iterate(ps, 4)
     cga.check(cga.lib().cgh_sync())
     pdt = time.perf_counter() - t0
+    p_spmv_ms = sv.spmv_ms()
     sv.free()
     out["parity_mode"] = {"value": ps / pdt, "unit": "iterations/s", "ms_per_step": pdt / ps * 1e3, "steps": ps,
-                          "note": "strict=1: dots and L1 norm in the reference's summation order (bit-identical trajectory)"}
+                          "note": "strict=1: dots and L1 norm in the reference's summation order (bit-identical trajectory)",
+                          "roofline": {"bound": "hbm", "kernel": "the same SpMV, leaving per-128-row sums of p.Ap for the order-exact walk",
+                                       "achieved": alg_spmv / (p_spmv_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                       "frac": alg_spmv / (p_spmv_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "ms_per_launch": p_spmv_ms}}
     if args.workload == "p7_256":
         out["multi_gpu_rehearsal"] = rehearse_inner_rank(nx, ny, nz, points, 8, args.steps / dt)
         out["multi_gpu_rehearsal"]["of_4"] = rehearse_inner_rank(nx, ny, nz, points, 4, args.steps / dt)

@@ -8,7 +8,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libcg_hip.so")
 
-LAYOUT_ELL, LAYOUT_CSR, LAYOUT_SELL = 0, 1, 2
+LAYOUT_ELL, LAYOUT_CSR, LAYOUT_SELL, LAYOUT_CSRB, LAYOUT_SELLS = 0, 1, 2, 3, 4
 
 dp = C.POINTER(C.c_double)
 ip = C.POINTER(C.c_int)
@@ -62,6 +62,10 @@ def lib():
     L.cgh_matrix_min_row.argtypes = [vp]
     L.cgh_matrix_set_exact_rows.argtypes = [vp, C.c_int]
     L.cgh_matrix_dict_offsets.argtypes = [vp]
+    L.cgh_config_csrb.argtypes = [C.c_int] * 6
+    L.cgh_config_sell_sigma.argtypes = [C.c_int]
+    L.cgh_csrb_plan_host.argtypes = [i64, ip, C.c_int, ip, ip]
+    L.cgh_csrb_plan_host.restype = i64
     L.cgh_matrix_free.argtypes = [vp]
     L.cgh_matrix_free.restype = None
     for f in ("cgh_matrix_rows", "cgh_matrix_nnz_offdiag", "cgh_matrix_stored_bytes"):
@@ -71,6 +75,7 @@ def lib():
         getattr(L, f).argtypes = [vp]
     L.cgh_matrix_download_ell.argtypes = [vp, dp, ip]
     L.cgh_matrix_download_diag.argtypes = [vp, dp]
+    L.cgh_matrix_download_csr.argtypes = [vp, C.POINTER(C.c_int64), ip, dp]
     L.cgh_spmv.argtypes = [vp, vp, vp]
     L.cgh_dot.argtypes = [vp, vp, i64, C.c_int, dp]
     L.cgh_l1norm.argtypes = [vp, i64, C.c_int, dp]
@@ -138,6 +143,7 @@ def lib():
     L.cgh_time_spmv.argtypes = [vp, vp, vp, C.c_int, dp]
     L.cgh_time_copy.argtypes = [vp, vp, C.c_size_t, C.c_int, dp]
     L.cgh_time_read.argtypes = [vp, vp, C.c_size_t, C.c_int, dp]
+    L.cgh_time_read_8_4.argtypes = [vp, vp, vp, C.c_size_t, C.c_int, dp]
     L.cgh_xsum_set_prof.argtypes = [vp]
     L.cgh_xsum_set_prof.restype = None
     _lib = L
@@ -147,6 +153,24 @@ def lib():
 def check(rc, what="libcg_hip call"):
     if rc != 0:
         raise RuntimeError("%s failed (%d): %s" % (what, rc, lib().cgh_last_error().decode()))
+
+
+def config_csrb(rows_per_wave_block=0, slab_bits=0, wgs_per_cu=0, window=-1, quorum_div=0, lds_atomics=-1):
+    """tuning of the column-blocked CSR matrices constructed after the call (see cgh_config_csrb in include/cg_hip.h)"""
+    check(lib().cgh_config_csrb(rows_per_wave_block, slab_bits, wgs_per_cu, window, quorum_div, lds_atomics), "cgh_config_csrb")
+
+
+def config_sell_sigma(sigma):
+    check(lib().cgh_config_sell_sigma(sigma), "cgh_config_sell_sigma")
+
+
+def csrb_plan(weights, spb):
+    """host-side planner of the column-blocked CSR -> (nblocks, seg_block, seg_slot)"""
+    w = np.ascontiguousarray(weights, dtype=np.int32)
+    sb = np.empty(w.size, dtype=np.int32)
+    ss = np.empty(w.size, dtype=np.int32)
+    nb = lib().cgh_csrb_plan_host(w.size, _I(w), spb, _I(sb), _I(ss))
+    return nb, sb, ss
 
 
 def have_gpu():
@@ -247,6 +271,14 @@ class Matrix:
         ec = np.empty(self.n * self.K, dtype=np.int32)
         check(lib().cgh_matrix_download_ell(self.h, _D(ev), _I(ec)), "download_ell")
         return ev, ec
+
+    def download_csr(self):
+        """CSR layout: (row_ptr int64 [n+1], cols int32, vals) of the full rows as stored"""
+        rp = np.empty(self.n + 1, dtype=np.int64)
+        cols = np.empty(self.nnz_offdiag, dtype=np.int32)
+        vals = np.empty(self.nnz_offdiag)
+        check(lib().cgh_matrix_download_csr(self.h, rp.ctypes.data_as(C.POINTER(C.c_int64)), _I(cols), _D(vals)), "download_csr")
+        return rp, cols, vals
 
     def download_diag(self):
         d = np.empty(self.n)

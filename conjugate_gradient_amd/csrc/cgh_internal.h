@@ -81,7 +81,33 @@ struct cgh_matrix {
     mutable int            dict_mode = 0;      // 1: cols8 = one byte per entry (slot-major); 2: 4 slots of a row per 32-bit word
     bool     owns = true;
     bool     exact_rows = false;  // CSR: add every row's products strictly left to right, however long the row is
+    // CSRB (column-blocked CSR, spmv_csrb.hip): rows are dealt in 64-row segments to wave-blocks of rpw rows holding about
+    // equal numbers of entries; a block's entries are sorted by (column slab of 2^cb_bits columns, local row) and stored as
+    // vals[] + cols[] reinterpreted as packed words (local row << cb_bits | column inside the slab)
+    int      cb_bits = 0, nslabs = 0, rpw = 0;
+    int64_t  nblocks = 0;
+    int     *blk_seg = nullptr;    // [nblocks * rpw/64] first row of each segment of the block, -1 = none
+    int64_t *blk_base = nullptr;   // [nblocks + 1] entry offsets of the blocks
+    int     *tile_off = nullptr;   // [nblocks * (nslabs + 1)] start of each slab's entries, relative to blk_base[b]
+    unsigned *gate_prog = nullptr; // progress counters of the sweep's pacing (zeroed before every launch)
+    int      gate_window = 0;      // pacing word: window (slabs a wave may run ahead; 0 = no pacing) | quorum divisor << 8 | LDS atomics << 16
+    // SELLS (sigma-sorted sliced ELL): rows sorted by length inside windows of sigma rows before slicing;
+    // perm[p] = row stored at position p (slice p/64, lane p%64), -1 beyond the last row
+    int     *perm = nullptr;
+    int      sigma = 0;
 };
+
+// Knobs read from the environment ONCE, in cgh_init (never in a launch path); cgh_config_* setters override them.
+struct cgh_config {
+    int csrb_rpw = 1024;        // CGH_CSRB_RPW: rows per wave-block of the column-blocked CSR (512 | 1024 | 2048)
+    int csrb_slab_bits = 17;    // CGH_CSRB_SLAB_BITS: log2 of the columns per slab (2^17 doubles = 1 MiB of x)
+    int csrb_wgs_per_cu = 0;    // CGH_CSRB_WGS: workgroups per CU of the column-blocked kernel (0 = what LDS admits)
+    int csrb_window = 3;        // CGH_CSRB_WINDOW: slabs a wave may run ahead of the pack (0 = no pacing)
+    int csrb_quorum_div = 2;    // CGH_CSRB_QUORUM: a gate opens once all but 1/div of the group's workgroups have passed
+    int csrb_lds_atomics = 0;   // CGH_CSRB_LDS_ATOMICS: row sums by LDS atomics instead of segmented scan + read-add-write
+    int sell_sigma = 65536;     // CGH_SELL_SIGMA: sorting window (rows) of the sigma-sorted sliced ELL
+};
+extern cgh_config g_cfg;
 
 // ------------------------------------------------------------ launch shapes
 constexpr int CGH_BLOCK = 256;          // 4 waves of 64

@@ -22,6 +22,10 @@
 // leaves what it wrote: `limit_seq` reproduces that (only placements with seq < limit are made).
 #include <vector>
 
+#include <cstring>
+
+#include <rocprim/device/device_radix_sort.hpp>
+
 #include "cgh_internal.h"
 
 // ------------------------------------------------------------------------------------ scans
@@ -209,6 +213,7 @@ struct out_desc {
     void    *cols;           // int* or uint64_t*
     const int64_t *row_ptr;  // CSR destination offsets (= bucket offsets)
     const int64_t *slice_ptr;  // SELL
+    const int     *row_pos = nullptr;  // sigma-sorted SELL: position (slice*64 + lane) of each row; NULL = the row itself
 };
 
 template <typename ColT>
@@ -226,7 +231,11 @@ __device__ __forceinline__ void place_one(const out_desc &o, int r, int slot, do
         at = (int64_t)r * o.K + slot;
         break;
     case OUT_CSR: at = o.row_ptr[r] + slot; break;
-    default: at = o.slice_ptr[r >> 6] + (int64_t)slot * 64 + (r & 63); break;
+    default: {
+        const int p = o.row_pos ? o.row_pos[r] : r;
+        at = o.slice_ptr[p >> 6] + (int64_t)slot * 64 + (p & 63);
+        break;
+    }
     }
     o.vals[at] = v;
     reinterpret_cast<ColT *>(o.cols)[at] = (ColT)c;
@@ -264,11 +273,13 @@ __global__ __launch_bounds__(256) void fill_pad(int64_t total, double *__restric
 }
 
 // SELL: width of slice s = max count over its 64 rows; stored entries of the slice = 64*width
-__global__ __launch_bounds__(256) void slice_sizes(int64_t n, const int *__restrict__ cnt, int64_t nslices, int64_t *__restrict__ sizes)
+__global__ __launch_bounds__(256) void slice_sizes(int64_t n, const int *__restrict__ cnt, int64_t nslices, int64_t *__restrict__ sizes,
+                                                  const int *__restrict__ perm)
 {
     const int64_t s = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (s >= nslices) return;
-    const int64_t r = s * 64 + (threadIdx.x & 63);
+    int64_t r = s * 64 + (threadIdx.x & 63);
+    if (perm != nullptr) r = perm[r] < 0 ? n : perm[r];
     int           m = r < n ? cnt[r] : 0;
     for (int off = 32; off > 0; off >>= 1) {
         const int o = __shfl_down(m, off, 64);
@@ -313,7 +324,7 @@ __global__ __launch_bounds__(256) void count_nonpad(int64_t total, const int *__
 __global__ __launch_bounds__(256) void to_ell_rows(int64_t n, int K, int layout, const double *__restrict__ vals,
                                                   const int *__restrict__ cols, const int64_t *__restrict__ row_ptr,
                                                   const int64_t *__restrict__ slice_ptr, double *__restrict__ ev,
-                                                  int *__restrict__ ec)
+                                                  int *__restrict__ ec, const int *__restrict__ row_pos)
 {
     for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < n; r += (int64_t)gridDim.x * 256) {
         int slot = 0;
@@ -323,12 +334,13 @@ __global__ __launch_bounds__(256) void to_ell_rows(int64_t n, int K, int layout,
                 ec[(int64_t)slot * n + r] = cols[q];
             }
         } else {
-            const int64_t b = slice_ptr[r >> 6];
-            const int     w = (int)((slice_ptr[(r >> 6) + 1] - b) >> 6);
+            const int64_t p = row_pos ? row_pos[r] : r;
+            const int64_t b = slice_ptr[p >> 6];
+            const int     w = (int)((slice_ptr[(p >> 6) + 1] - b) >> 6);
             for (int t = 0; t < w; ++t) {
-                const int c = cols[b + (int64_t)t * 64 + (r & 63)];
+                const int c = cols[b + (int64_t)t * 64 + (p & 63)];
                 if (c == -1) continue;
-                ev[(int64_t)slot * n + r] = vals[b + (int64_t)t * 64 + (r & 63)];
+                ev[(int64_t)slot * n + r] = vals[b + (int64_t)t * 64 + (p & 63)];
                 ec[(int64_t)slot * n + r] = c;
                 ++slot;
             }
@@ -352,6 +364,48 @@ __global__ __launch_bounds__(256) void min_row_length(int64_t n, const int64_t *
         m = o < m ? o : m;
     }
     if ((threadIdx.x & 63) == 0) atomicMin(result, m);
+}
+
+// sigma-sorted SELL: key = (window, descending length), value = row; a stable sort leaves equal lengths in row order
+__global__ __launch_bounds__(256) void sigma_keys(int64_t n, int sigma, const int *__restrict__ cnt, unsigned long long *__restrict__ keys,
+                                                 int *__restrict__ rows)
+{
+    for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < n; r += (int64_t)gridDim.x * 256) {
+        keys[r] = ((unsigned long long)(r / sigma) << 32) | (unsigned long long)(0xffffffffu - (unsigned)cnt[r]);
+        rows[r] = (int)r;
+    }
+}
+
+// perm[p] = row at position p (padded with -1 up to a whole slice); pos[row] = p
+__global__ __launch_bounds__(256) void sigma_positions(int64_t n, int64_t padded, const int *__restrict__ sorted_rows, int *__restrict__ perm,
+                                                      int *__restrict__ pos)
+{
+    for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < padded; p += (int64_t)gridDim.x * 256) {
+        const int r = p < n ? sorted_rows[p] : -1;
+        perm[p] = r;
+        if (r >= 0 && pos != nullptr) pos[r] = (int)p;
+    }
+}
+
+// slices by descending stored size (stable: equal sizes stay in window order)
+__global__ __launch_bounds__(256) void slice_keys(int64_t ns, const int64_t *__restrict__ sizes, unsigned long long *__restrict__ keys,
+                                                 int *__restrict__ ids)
+{
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < ns; t += (int64_t)gridDim.x * 256) {
+        keys[t] = ~(unsigned long long)sizes[t];
+        ids[t] = (int)t;
+    }
+}
+
+// slice t of the final order is slice order[t] of the window order; pos[row] = its final position
+__global__ __launch_bounds__(256) void permute_slices(int64_t ns, const int *__restrict__ order, const int *__restrict__ perm_in,
+                                                     int *__restrict__ perm_out, int *__restrict__ pos)
+{
+    for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < ns * 64; p += (int64_t)gridDim.x * 256) {
+        const int r = perm_in[(int64_t)order[p >> 6] * 64 + (p & 63)];
+        perm_out[p] = r;
+        if (r >= 0) pos[r] = (int)p;
+    }
 }
 
 struct dev_buf {
@@ -556,15 +610,30 @@ int cgh_sort_coo_to_csr_device(int64_t n, int64_t nnz, const double *d_vals, con
 }
 
 int cgh_csr_build_row_blocks(cgh_matrix *m, hipStream_t s);  // spmv_csr.hip
+cgh_matrix *cgh_csrb_from_csr(cgh_matrix *csr);                // spmv_csrb.hip
 
 int cgh_csr_to_ell_download(const cgh_matrix *m, double *ell_vals, int *ell_cols)
 {
     const int64_t total = m->n * (int64_t)m->K;
     dev_buf       ev(sizeof(double) * (size_t)(total ? total : 1)), ec(sizeof(int) * (size_t)(total ? total : 1));
     if (!ev.p || !ec.p) return CGH_ENOMEM;
-    hipLaunchKernelGGL(to_ell_rows, dim3(grid_for(m->n)), dim3(256), 0, g_cgh.stream, m->n, m->K, m->layout,
-                       (const double *)m->vals, (const int *)m->cols, (const int64_t *)m->row_ptr,
-                       (const int64_t *)m->slice_ptr, ev.as<double>(), ec.as<int>());
+    if (m->layout == CGH_LAYOUT_CSRB) {
+        cgh_set_error("cgh_matrix_download_ell: the column-blocked layout does not keep the rows' original entry order");
+        return CGH_EINVAL;
+    }
+    dev_buf pos(sizeof(int) * (size_t)m->n);
+    if (!pos.p) return CGH_ENOMEM;
+    if (m->perm != nullptr) {
+        dev_buf scratch(sizeof(int) * (size_t)(m->nslices * 64));
+        if (!scratch.p) return CGH_ENOMEM;
+        hipLaunchKernelGGL(sigma_positions, dim3(grid_for(m->nslices * 64)), dim3(256), 0, g_cgh.stream, m->nslices * 64, m->nslices * 64,
+                           (const int *)m->perm, scratch.as<int>(), pos.as<int>());
+        CGH_HIP(hipStreamSynchronize(g_cgh.stream));
+    }
+    hipLaunchKernelGGL(to_ell_rows, dim3(grid_for(m->n)), dim3(256), 0, g_cgh.stream, m->n, m->K,
+                       m->layout == CGH_LAYOUT_CSR ? CGH_LAYOUT_CSR : CGH_LAYOUT_SELL, (const double *)m->vals, (const int *)m->cols,
+                       (const int64_t *)m->row_ptr, (const int64_t *)m->slice_ptr, ev.as<double>(), ec.as<int>(),
+                       m->perm ? (const int *)pos.p : (const int *)nullptr);
     CGH_HIP(hipGetLastError());
     int rc = cgh_d2h(ell_vals, ev.p, sizeof(double) * (size_t)total);
     if (rc) return rc;
@@ -610,7 +679,11 @@ cgh_matrix *cgh_matrix_from_entries_device(int64_t n, int64_t U, const double *d
 {
     CGH_REQUIRE_READY(nullptr);
     const bool inline_diag = d_diag == nullptr;
-    if (n <= 0 || U < 0 || (U > 0 && (!d_upper || !d_rows || !d_cols)) || layout < 0 || layout > 2) {
+    if (layout == CGH_LAYOUT_CSRB) {
+        cgh_matrix *csr = cgh_matrix_from_entries_device(n, U, d_diag, d_upper, d_rows, d_cols, CGH_LAYOUT_CSR);
+        return csr ? cgh_csrb_from_csr(csr) : nullptr;
+    }
+    if (n <= 0 || U < 0 || (U > 0 && (!d_upper || !d_rows || !d_cols)) || layout < 0 || layout > CGH_LAYOUT_SELLS) {
         cgh_set_error("cgh_matrix_from_coo: bad arguments (n=%lld U=%lld layout=%d)", (long long)n, (long long)U, layout);
         return nullptr;
     }
@@ -636,6 +709,7 @@ cgh_matrix *cgh_matrix_from_entries_device(int64_t n, int64_t U, const double *d
     o.K = m->K;
     o.row_ptr = B.row_ptr;
     o.slice_ptr = nullptr;
+    dev_buf row_pos(0);  // sigma-sorted SELL: position of each row (construction only)
     if (ok && layout == CGH_LAYOUT_ELL) {
         m->stored = n * (int64_t)m->K;
         o.mode = OUT_ELL_SLOT_MAJOR;
@@ -649,9 +723,62 @@ cgh_matrix *cgh_matrix_from_entries_device(int64_t n, int64_t U, const double *d
         m->nslices = (n + 63) / 64;
         m->slice_ptr = (int64_t *)cgh_alloc(sizeof(int64_t) * (size_t)(m->nslices + 2));
         ok = m->slice_ptr != nullptr;
+        if (ok && layout == CGH_LAYOUT_SELLS) {
+            // rows sorted by descending length inside windows of sigma rows (stable: equal lengths stay in row order)
+            m->sigma = g_cfg.sell_sigma < 64 ? 64 : g_cfg.sell_sigma;
+            m->perm = (int *)cgh_alloc(sizeof(int) * (size_t)(m->nslices * 64));
+            cgh_free(row_pos.p);
+            row_pos.p = cgh_alloc(sizeof(int) * (size_t)n);
+            dev_buf k0(sizeof(unsigned long long) * (size_t)n), k1(sizeof(unsigned long long) * (size_t)n), r0(sizeof(int) * (size_t)n),
+                r1(sizeof(int) * (size_t)n);
+            ok = m->perm && row_pos.p && k0.p && k1.p && r0.p && r1.p;
+            if (ok) {
+                hipLaunchKernelGGL(sigma_keys, dim3(grid_for(n)), dim3(256), 0, s, n, m->sigma, (const int *)B.cnt,
+                                   k0.as<unsigned long long>(), r0.as<int>());
+                size_t     tmp_bytes = 0;
+                hipError_t he = rocprim::radix_sort_pairs(nullptr, tmp_bytes, k0.as<unsigned long long>(), k1.as<unsigned long long>(),
+                                                          r0.as<int>(), r1.as<int>(), (size_t)n, 0u, 64u, s);
+                dev_buf    tmp(tmp_bytes ? tmp_bytes : 16);
+                ok = he == hipSuccess && tmp.p;
+                if (ok)
+                    he = rocprim::radix_sort_pairs(tmp.p, tmp_bytes, k0.as<unsigned long long>(), k1.as<unsigned long long>(), r0.as<int>(),
+                                                   r1.as<int>(), (size_t)n, 0u, 64u, s);
+                ok = ok && he == hipSuccess;
+                // slices (64 consecutive sorted rows) ordered by descending width over the whole matrix, so that the
+                // SpMV's round-robin deal of slices to waves gives every wave the same mix of wide and narrow ones
+                // (in window order the few very wide slices of all windows met on the same 32 waves: 23 ms per SpMV)
+                const int64_t ns = m->nslices;
+                dev_buf       ptmp(sizeof(int) * (size_t)(ns * 64)), sz(sizeof(int64_t) * (size_t)(ns + 1)),
+                    sk0(sizeof(unsigned long long) * (size_t)ns), sk1(sizeof(unsigned long long) * (size_t)ns), so0(sizeof(int) * (size_t)ns),
+                    so1(sizeof(int) * (size_t)ns);
+                ok = ok && ptmp.p && sz.p && sk0.p && sk1.p && so0.p && so1.p;
+                if (ok) {
+                    hipLaunchKernelGGL(sigma_positions, dim3(grid_for(ns * 64)), dim3(256), 0, s, n, ns * 64, (const int *)r1.p,
+                                       ptmp.as<int>(), (int *)nullptr);
+                    hipLaunchKernelGGL(slice_sizes, dim3((unsigned)((ns + 3) / 4)), dim3(256), 0, s, n, (const int *)B.cnt, ns,
+                                       sz.as<int64_t>(), (const int *)ptmp.p);
+                    hipLaunchKernelGGL(slice_keys, dim3(grid_for(ns)), dim3(256), 0, s, ns, (const int64_t *)sz.p,
+                                       sk0.as<unsigned long long>(), so0.as<int>());
+                    size_t stmp = 0;
+                    he = rocprim::radix_sort_pairs(nullptr, stmp, sk0.as<unsigned long long>(), sk1.as<unsigned long long>(), so0.as<int>(),
+                                                   so1.as<int>(), (size_t)ns, 0u, 64u, s);
+                    dev_buf tmp2(stmp ? stmp : 16);
+                    ok = he == hipSuccess && tmp2.p;
+                    if (ok)
+                        he = rocprim::radix_sort_pairs(tmp2.p, stmp, sk0.as<unsigned long long>(), sk1.as<unsigned long long>(), so0.as<int>(),
+                                                       so1.as<int>(), (size_t)ns, 0u, 64u, s);
+                    ok = ok && he == hipSuccess;
+                    if (ok)
+                        hipLaunchKernelGGL(permute_slices, dim3(grid_for(ns * 64)), dim3(256), 0, s, ns, (const int *)so1.p,
+                                           (const int *)ptmp.p, m->perm, row_pos.as<int>());
+                    ok = ok && hipStreamSynchronize(s) == hipSuccess;
+                }
+            }
+            o.row_pos = row_pos.as<int>();
+        }
         if (ok) {
             hipLaunchKernelGGL(slice_sizes, dim3((unsigned)((m->nslices + 3) / 4)), dim3(256), 0, s, n, (const int *)B.cnt, m->nslices,
-                               m->slice_ptr);
+                               m->slice_ptr, (const int *)m->perm);
             int64_t total = 0;
             ok = cgh_exclusive_scan_i64(m->slice_ptr, m->slice_ptr, m->nslices, &total, s) == CGH_OK;
             m->stored = total;

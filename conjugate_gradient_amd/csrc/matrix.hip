@@ -9,6 +9,8 @@ int cgh_launch_spmv_csr(const cgh_matrix *m, const double *x, double *y, double 
                         const int *done, hipStream_t s);
 int cgh_launch_spmv_sell(const cgh_matrix *m, const double *x, double *y, double *dot_partials, int *grid_out,
                          const int *done, hipStream_t s);
+int cgh_launch_spmv_csrb(const cgh_matrix *m, const double *x, double *y, double *dot_partials, int *grid_out,
+                         const int *done, hipStream_t s);
 int cgh_csr_to_ell_download(const cgh_matrix *m, double *ell_vals, int *ell_cols);
 
 int cgh_launch_spmv(const cgh_matrix *m, const double *x, double *y, double *dot_partials, int *grid_out,
@@ -17,7 +19,9 @@ int cgh_launch_spmv(const cgh_matrix *m, const double *x, double *y, double *dot
     switch (m->layout) {
     case CGH_LAYOUT_ELL: return cgh_launch_spmv_ell(m, x, y, dot_partials, grid_out, done, s);
     case CGH_LAYOUT_CSR: return cgh_launch_spmv_csr(m, x, y, dot_partials, grid_out, done, s);
-    case CGH_LAYOUT_SELL: return cgh_launch_spmv_sell(m, x, y, dot_partials, grid_out, done, s);
+    case CGH_LAYOUT_SELL:
+    case CGH_LAYOUT_SELLS: return cgh_launch_spmv_sell(m, x, y, dot_partials, grid_out, done, s);
+    case CGH_LAYOUT_CSRB: return cgh_launch_spmv_csrb(m, x, y, dot_partials, grid_out, done, s);
     }
     cgh_set_error("cgh_spmv: unknown layout %d", m->layout);
     return CGH_EINVAL;
@@ -49,9 +53,46 @@ __global__ __launch_bounds__(256) void read16(const u4_t *__restrict__ src, unsi
     if (acc == 0x9e3779b9u) sink[blockIdx.x] = acc;  // (practically never: keeps the loads alive)
 }
 
+// the same with 8-byte and 4-byte loads per lane (the access widths of the CSR-family kernels): calibrates FETCH_SIZE
+__global__ __launch_bounds__(256) void read8_4(const unsigned long long *__restrict__ src8, const unsigned *__restrict__ src4,
+                                               unsigned *__restrict__ sink, size_t count)
+{
+    unsigned long long acc = 0;
+    const size_t       stride = (size_t)gridDim.x * 256;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < count; i += stride)
+        acc ^= __builtin_nontemporal_load(src8 + i) ^ (unsigned long long)__builtin_nontemporal_load(src4 + i);
+    if (acc == 0x9e3779b97f4a7c15ull) sink[blockIdx.x] = (unsigned)acc;
+}
+
 } // namespace
 
 extern "C" {
+
+// `count` 8-byte words from d_src8 and `count` 4-byte words from d_src4, one of each per lane and step (12 bytes per lane,
+// as the CSR-family kernels stream a matrix): a calibration stream for the FETCH_SIZE counter.
+int cgh_time_read_8_4(const void *d_src8, const void *d_src4, void *d_sink_8k, size_t count, int reps, double *ms_avg)
+{
+    CGH_REQUIRE_READY(CGH_ENODEV);
+    if (reps < 1 || !d_src8 || !d_src4 || !d_sink_8k) return CGH_EINVAL;
+    hipStream_t s = g_cgh.stream;
+    hipEvent_t  a, b;
+    CGH_HIP(hipEventCreate(&a));
+    CGH_HIP(hipEventCreate(&b));
+    const int grid = g_cgh.num_cu * 8;
+    if (grid > 2048) return CGH_EINVAL;
+    CGH_HIP(hipEventRecord(a, s));
+    for (int k = 0; k < reps; ++k)
+        hipLaunchKernelGGL(read8_4, dim3(grid), dim3(256), 0, s, (const unsigned long long *)d_src8, (const unsigned *)d_src4,
+                           (unsigned *)d_sink_8k, count);
+    CGH_HIP(hipEventRecord(b, s));
+    CGH_HIP(hipStreamSynchronize(s));
+    float ms = 0.f;
+    CGH_HIP(hipEventElapsedTime(&ms, a, b));
+    (void)hipEventDestroy(a);
+    (void)hipEventDestroy(b);
+    *ms_avg = (double)ms / reps;
+    return CGH_OK;
+}
 
 cgh_matrix *cgh_matrix_from_ell_host(int64_t n, int K, const double *diag, const double *ell_vals, const int *ell_cols)
 {
@@ -93,6 +134,11 @@ void cgh_matrix_free(cgh_matrix *m)
         cgh_free(m->row_ptr);
         cgh_free(m->slice_ptr);
         cgh_free(m->bin_rows);
+        cgh_free(m->blk_seg);
+        cgh_free(m->blk_base);
+        cgh_free(m->tile_off);
+        cgh_free(m->gate_prog);
+        cgh_free(m->perm);
     }
     cgh_ell_dict_free(m);
     delete m;
@@ -109,6 +155,8 @@ int64_t cgh_matrix_stored_bytes(const cgh_matrix *m)
     int64_t b = m->stored * 12 + m->n * 8;
     if (m->layout == CGH_LAYOUT_CSR) b += (m->n + 1) * 8;
     if (m->layout == CGH_LAYOUT_SELL) b += (m->nslices + 1) * 8;
+    if (m->layout == CGH_LAYOUT_SELLS) b += (m->nslices + 1) * 8 + m->nslices * 64 * 4;
+    if (m->layout == CGH_LAYOUT_CSRB) b += (m->nblocks + 1) * 8 + m->nblocks * (int64_t)(m->nslabs + 1) * 4 + m->nblocks * (m->rpw / 64) * 4;
     return b;
 }
 
@@ -128,6 +176,21 @@ int cgh_matrix_download_ell(const cgh_matrix *m, double *ell_vals, int *ell_cols
         return cgh_d2h(ell_cols, m->cols, sizeof(int) * (size_t)m->stored);
     }
     return cgh_csr_to_ell_download(m, ell_vals, ell_cols);
+}
+
+// CSR layout only: the full rows as stored (row_ptr[n+1] 64-bit, cols / vals [nnz_offdiag]), in the reference's
+// per-row accumulation order.
+int cgh_matrix_download_csr(const cgh_matrix *m, int64_t *row_ptr, int *cols, double *vals)
+{
+    CGH_REQUIRE_READY(CGH_ENODEV);
+    if (!m || m->layout != CGH_LAYOUT_CSR || !row_ptr || !cols || !vals) {
+        cgh_set_error("cgh_matrix_download_csr: needs a CGH_LAYOUT_CSR matrix and three host buffers");
+        return CGH_EINVAL;
+    }
+    int rc = cgh_d2h(row_ptr, m->row_ptr, sizeof(int64_t) * (size_t)(m->n + 1));
+    if (rc == CGH_OK) rc = cgh_d2h(cols, m->cols, sizeof(int) * (size_t)m->nnz_off);
+    if (rc == CGH_OK) rc = cgh_d2h(vals, m->vals, sizeof(double) * (size_t)m->nnz_off);
+    return rc;
 }
 
 int cgh_spmv(const cgh_matrix *m, const double *d_x, double *d_y)

@@ -51,6 +51,16 @@ int cgh_init(int device)
         return CGH_ENODEV;
     }
     g_cgh.num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    // knobs: the environment is read here, once, never in a launch path
+    auto env_int = [](const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; };
+    g_cfg = cgh_config();
+    g_cfg.csrb_rpw = env_int("CGH_CSRB_RPW", g_cfg.csrb_rpw);
+    g_cfg.csrb_slab_bits = env_int("CGH_CSRB_SLAB_BITS", g_cfg.csrb_slab_bits);
+    g_cfg.csrb_wgs_per_cu = env_int("CGH_CSRB_WGS", g_cfg.csrb_wgs_per_cu);
+    g_cfg.csrb_window = env_int("CGH_CSRB_WINDOW", g_cfg.csrb_window);
+    g_cfg.csrb_quorum_div = env_int("CGH_CSRB_QUORUM", g_cfg.csrb_quorum_div);
+    g_cfg.csrb_lds_atomics = env_int("CGH_CSRB_LDS_ATOMICS", g_cfg.csrb_lds_atomics);
+    g_cfg.sell_sigma = env_int("CGH_SELL_SIGMA", g_cfg.sell_sigma);
     CGH_HIP(hipStreamCreateWithFlags(&g_cgh.stream, hipStreamNonBlocking));
     CGH_HIP(hipStreamCreateWithFlags(&g_cgh.comm_stream, hipStreamNonBlocking));
     g_cgh.device = device;
@@ -67,6 +77,13 @@ void cgh_shutdown(void)
     g_cgh.stream = g_cgh.comm_stream = nullptr;
     g_cgh.ready = false;
     g_cgh.device = -1;
+}
+
+int cgh_config_sell_sigma(int sigma_rows)
+{
+    if (sigma_rows < 0) return CGH_EINVAL;
+    if (sigma_rows) g_cfg.sell_sigma = sigma_rows < 64 ? 64 : sigma_rows;
+    return CGH_OK;
 }
 
 int cgh_sync(void)

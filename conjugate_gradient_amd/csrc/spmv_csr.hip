@@ -138,7 +138,7 @@ __global__ __launch_bounds__(CGH_BLOCK) void spmv_sell64(int64_t n, int64_t nsli
                                                         const double *__restrict__ diag, const double *__restrict__ vals,
                                                         const int *__restrict__ cols, const double *__restrict__ x,
                                                         double *__restrict__ y, double *__restrict__ partials,
-                                                        const int *__restrict__ done)
+                                                        const int *__restrict__ done, const int *__restrict__ perm)
 {
     __shared__ double red[4];
     if (done != nullptr && *done != 0) return;
@@ -147,8 +147,9 @@ __global__ __launch_bounds__(CGH_BLOCK) void spmv_sell64(int64_t n, int64_t nsli
     for (int64_t s = (int64_t)blockIdx.x * 4 + wave; s < nslices; s += (int64_t)gridDim.x * 4) {
         const int64_t b = slice_ptr[s];
         const int     w = (int)((slice_ptr[s + 1] - b) >> 6);
-        const int64_t r = s * 64 + lane;
-        if (r >= n) continue;
+        // sigma-sorted slices: the lane's row comes from the permutation (-1 = no row)
+        const int64_t r = perm != nullptr ? (int64_t)perm[s * 64 + lane] : s * 64 + lane;
+        if (r < 0 || r >= n) continue;
         const double xr = x[r];
         double       acc = add_rn(0.0, mul_rn(diag[r], xr));
 #pragma unroll 4
@@ -242,10 +243,12 @@ int cgh_launch_spmv_sell(const cgh_matrix *m, const double *x, double *y, double
     if (grid_out) *grid_out = grid;
     if (dot_partials)
         hipLaunchKernelGGL(spmv_sell64<true>, dim3(grid), dim3(CGH_BLOCK), 0, s, m->n, m->nslices, (const int64_t *)m->slice_ptr,
-                           (const double *)m->diag, (const double *)m->vals, (const int *)m->cols, x, y, dot_partials, done);
+                           (const double *)m->diag, (const double *)m->vals, (const int *)m->cols, x, y, dot_partials, done,
+                           (const int *)m->perm);
     else
         hipLaunchKernelGGL(spmv_sell64<false>, dim3(grid), dim3(CGH_BLOCK), 0, s, m->n, m->nslices, (const int64_t *)m->slice_ptr,
-                           (const double *)m->diag, (const double *)m->vals, (const int *)m->cols, x, y, (double *)nullptr, done);
+                           (const double *)m->diag, (const double *)m->vals, (const int *)m->cols, x, y, (double *)nullptr, done,
+                           (const int *)m->perm);
     CGH_HIP(hipGetLastError());
     return CGH_OK;
 }

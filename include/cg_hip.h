@@ -62,7 +62,13 @@ typedef struct cgh_matrix cgh_matrix;
 enum {
     CGH_LAYOUT_ELL = 0,   /* slot-major full ELL: entry (row i, slot s) at s*n+i; pad = value 0.0, col -1 (reference ell.c:791-858 layout) */
     CGH_LAYOUT_CSR = 1,   /* full (both triangles) CSR, int64 row_ptr, rows in reference accumulation order; vector/adaptive kernels */
-    CGH_LAYOUT_SELL = 2   /* sliced ELL: slices of 64 rows, each padded to its own width, slot-major inside the slice */
+    CGH_LAYOUT_SELL = 2,  /* sliced ELL: slices of 64 rows, each padded to its own width, slot-major inside the slice */
+    CGH_LAYOUT_CSRB = 3,  /* column-blocked CSR (throughput layout for skewed rows / scattered columns, BASELINE config 5):
+                             rows dealt in 64-row segments to wave-blocks of equal weight, a block's entries sorted by
+                             column slab so that every wave on the chip gathers from the same ~1 MiB window of x at the
+                             same time; per-row sums in a fixed order (deterministic) that is NOT the reference's order */
+    CGH_LAYOUT_SELLS = 4  /* sigma-sorted sliced ELL (SELL-C-sigma, C = 64): rows sorted by length inside windows of
+                             sigma rows before slicing, the permutation folded into y; per-row order = the reference's */
 };
 
 /* Host slot-major full ELL (what coo_to_ell_symmetric_full_colmajor produced) -> device. */
@@ -90,6 +96,18 @@ int     cgh_matrix_min_row(const cgh_matrix *m);      /* shortest row of a CSR-l
 /* CSR layout: 1 = every row's products are added strictly left to right (the reference's order) however long the row;
  * 0 (default) = rows of more than 64 entries use a wave/workgroup tree.  The include/cg.h, csr.h, coo.h entry points set 1. */
 int     cgh_matrix_set_exact_rows(cgh_matrix *m, int exact);
+/* Tuning of the CGH_LAYOUT_CSRB / CGH_LAYOUT_SELLS matrices constructed AFTER the call (0 keeps the current value unless
+ * stated): rows per wave-block (512 | 1024 | 2048); log2 of the columns per slab (4..22); workgroups per CU (0 = what
+ * LDS admits); pacing of the sweep over x: slabs a wave may run ahead of its group (0 = no pacing, < 0 keeps) and the
+ * quorum divisor d (a gate opens once all but 1/d of the group's workgroups have passed; 2..255); row sums by LDS
+ * atomics (1) or by segmented scan + read-add-write (0, the default: order fixed by construction; < 0 keeps).
+ * Sorting window (rows) of the sigma-sorted sliced ELL. */
+int     cgh_config_csrb(int rows_per_wave_block, int slab_bits, int wgs_per_cu, int window, int quorum_div, int lds_atomics);
+int     cgh_config_sell_sigma(int sigma_rows);
+/* Host-side planner of the column-blocked CSR (no GPU needed; exported for tests): deals nseg segments of the given
+ * weights (entries) to ceil(nseg/spb) blocks of at most spb segments each, heaviest first to the lightest block with a
+ * free slot.  seg_block[s], seg_slot[s] receive the placement.  Returns the number of blocks. */
+int64_t cgh_csrb_plan_host(int64_t nseg, const int *weights, int spb, int *seg_block, int *seg_slot);
 /* ELL layout: the SpMV reads 1-byte dictionary codes instead of 4-byte column ids when the matrix has at most 255
  * distinct (col - row) offsets (banded / stencil matrices; built on the first SpMV; CGH_ELL_DICT=0 disables).  Returns the
  * number of distinct offsets in use, 0 if the matrix does not qualify, -1 before the first SpMV / other layouts. */
@@ -97,6 +115,8 @@ int     cgh_matrix_dict_offsets(const cgh_matrix *m);
 /* Download as slot-major full ELL of width K=cgh_matrix_width (any layout); buffers hold n*K entries. */
 int     cgh_matrix_download_ell(const cgh_matrix *m, double *ell_vals, int *ell_cols);
 int     cgh_matrix_download_diag(const cgh_matrix *m, double *diag);
+/* CGH_LAYOUT_CSR only: the full rows as stored (row_ptr[n+1], cols / vals [cgh_matrix_nnz_offdiag]). */
+int     cgh_matrix_download_csr(const cgh_matrix *m, int64_t *row_ptr, int *cols, double *vals);
 
 /* ---- kernels ------------------------------------------------------------ */
 int cgh_spmv(const cgh_matrix *m, const double *d_x, double *d_y);           /* y = A x */
@@ -248,6 +268,9 @@ int cgh_time_copy(void *d_dst, const void *d_src, size_t bytes, int reps, double
 void cgh_xsum_set_prof(void *dev_16_words);
 /* read-only stream of `bytes` from d_src (d_sink_8k: 8 KiB of device scratch): the ceiling for read-dominated kernels */
 int cgh_time_read(const void *d_src, void *d_sink_8k, size_t bytes, int reps, double *ms_avg);
+/* `count` 8-byte words from d_src8 plus `count` 4-byte words from d_src4, one of each per lane and step (how the CSR-family
+ * kernels stream a matrix): a stream of known size that calibrates the FETCH_SIZE counter for those access widths */
+int cgh_time_read_8_4(const void *d_src8, const void *d_src4, void *d_sink_8k, size_t count, int reps, double *ms_avg);
 
 #ifdef __cplusplus
 }

@@ -94,19 +94,26 @@ def test_config4_full_size_spmv_property(cga):
 def test_config5_full_size_properties(cga):
     """BASELINE config 5 at its full size (8.4M rows, power-law row lengths 1..2000, ~75M off-diagonals): there is no
     reference output at this size (its conversion alone would take minutes on the host), so size-independent checks:
-    (1) the CSR stream/adaptive and the sliced-ELL kernels, with the reference's per-row order forced for long rows too,
-        give bit-identical y; (2) A*1 = 1 up to the rounding of one row (diag = 1 + sum|a_ij|, a_ij <= 0);
-    (3) symmetry: z.(A x) = x.(A z) to rounding."""
+    (1) the CSR stream/adaptive, the sliced-ELL and the sigma-sorted sliced-ELL kernels, with the reference's per-row
+        order forced for long rows too, give bit-identical y; the sigma-sorted slices store < 1.5x the CSR bytes where
+        plain slices store > 10x;
+    (2) A*1 = 1 up to the rounding of one row (diag = 1 + sum|a_ij|, a_ij <= 0);
+    (3) symmetry: z.(A x) = x.(A z) to rounding;
+    (4) the column-blocked CSR (throughput layout, fixed order that is not the reference's) agrees with (1) to a few
+        ulps of sum|a_ij x_j| per row, and gives the same bits on every run."""
     n, max_len, seed = 8 * 1024 * 1024, 2000, 0x5EED0005
     rng = np.random.default_rng(5)
     xh, zh = rng.standard_normal(n), rng.standard_normal(n)
     x, z, ones = cga.DeviceVector.from_host(xh), cga.DeviceVector.from_host(zh), cga.DeviceVector.from_host(np.ones(n))
-    ys = {}
-    for layout in (cga.LAYOUT_CSR, cga.LAYOUT_SELL):
+    ys, stored = {}, {}
+    cga.config_sell_sigma(65536)
+    cga.config_csrb(1024, 17, 0, 3, 2, 0)
+    for layout in (cga.LAYOUT_CSR, cga.LAYOUT_SELL, cga.LAYOUT_SELLS, cga.LAYOUT_CSRB):
         b = cga.DeviceVector(n)
         A = cga.Matrix.powerlaw(n, max_len, seed, layout, b)
         A.set_exact_rows(True)
         assert A.n == n and 1000 < A.K <= max_len + 48 and A.nnz_offdiag > 7 * n
+        stored[layout] = A.stored_bytes
         y = cga.DeviceVector(n)
         A.spmv(x, y); yx = y.to_host()
         A.spmv(ones, y); y1 = y.to_host()
@@ -117,7 +124,19 @@ def test_config5_full_size_properties(cga):
             assert np.max(np.abs(y1 - 1.0) / diag) < 1e-12                 # (2)
             lhs, rhs = float(zh @ yx), float(xh @ yz)
             assert abs(lhs - rhs) <= 1e-10 * (np.abs(zh) @ np.abs(yx))      # (3)
+            ax = cga.DeviceVector.from_host(np.abs(xh))
+            A.spmv(ax, y)                                                   # |A||x| = 2 diag|x| - A|x| (off-diagonals <= 0)
+            bound = 2.0 * diag * np.abs(xh) - y.to_host()
+        if layout == cga.LAYOUT_CSRB:
+            A.spmv(x, y)
+            assert np.array_equal(bits(y.to_host()), bits(yx))              # (4) deterministic
         ys[layout] = (yx, y1)
         A.free()
-    assert np.array_equal(bits(ys[cga.LAYOUT_CSR][0]), bits(ys[cga.LAYOUT_SELL][0]))   # (1)
-    assert np.array_equal(bits(ys[cga.LAYOUT_CSR][1]), bits(ys[cga.LAYOUT_SELL][1]))
+    for lay in (cga.LAYOUT_SELL, cga.LAYOUT_SELLS):                         # (1)
+        assert np.array_equal(bits(ys[cga.LAYOUT_CSR][0]), bits(ys[lay][0]))
+        assert np.array_equal(bits(ys[cga.LAYOUT_CSR][1]), bits(ys[lay][1]))
+    assert stored[cga.LAYOUT_SELLS] < 1.5 * stored[cga.LAYOUT_CSR] and stored[cga.LAYOUT_SELL] > 10 * stored[cga.LAYOUT_CSR]
+    assert stored[cga.LAYOUT_CSRB] < 1.05 * stored[cga.LAYOUT_CSR]
+    err = np.abs(ys[cga.LAYOUT_CSRB][0] - ys[cga.LAYOUT_CSR][0])            # (4)
+    assert np.all(err <= 64 * np.finfo(float).eps * bound), float((err / bound).max())
+    assert np.max(np.abs(ys[cga.LAYOUT_CSRB][1] - 1.0) / diag) < 1e-12
