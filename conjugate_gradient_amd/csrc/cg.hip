@@ -25,9 +25,6 @@
 #include "cgh_internal.h"
 #include "device_utils.h"
 
-int cgh_launch_spmv(const cgh_matrix *m, const double *x, double *y, double *dot_partials, int *grid_out,
-                    const int *done, hipStream_t s);
-
 #include "cg_kernels.h"
 
 namespace {
@@ -47,12 +44,7 @@ int vec_grid(int64_t n)
 
 // Vectors of at least this many elements take the order-exact PARALLEL sums of xsum.hip in strict mode; shorter ones
 // the single-lane seq_sums kernel (same bits either way).  CGH_XSUM_MIN_ROWS overrides (0 = always, -1 = never).
-int64_t xsum_min_rows()
-{
-    const char *e = getenv("CGH_XSUM_MIN_ROWS");
-    const int64_t v = e ? atoll(e) : 4096;  // measured crossover on MI355X (~70 us/iteration either way)
-    return v < 0 ? INT64_MAX : v;
-}
+int64_t xsum_min_rows() { return g_cfg.xsum_min_rows < 0 ? INT64_MAX : g_cfg.xsum_min_rows; }
 
 struct xsum_guard {
     cgh_xsum *w = nullptr;
@@ -102,6 +94,7 @@ struct cgh_solver {
     double           *partA = nullptr, *partB = nullptr, *hist = nullptr;
     int              *done = nullptr;
     cgh_xsum         *xs = nullptr;   // order-exact parallel sums (strict mode of long vectors), created on demand
+    bool              no_alloc = false;  // cgh_cg_solve_noalloc: no launch of this solver may allocate
     std::vector<hipEvent_t> kev;      // SpMV kernel brackets (time_kernels)
     // HIP graphs of `count` iterations (launch-bound sizes): kernels take the iteration number from the device
     std::vector<std::pair<int, hipGraphExec_t>> graphs;
@@ -236,7 +229,9 @@ int cgh_solver_start(cgh_solver *sv, const double *d_b, double *d_x, double tol,
     sv->graphs.clear();
     CGH_HIP(hipMemsetAsync(sv->done, 0, sizeof(int) * 4, s));
     CGH_HIP(hipMemsetAsync(d_x, 0, sizeof(double) * (size_t)n, s));
-    int rc = cgh_launch_spmv(sv->m, d_x, sv->Ap, nullptr, nullptr, nullptr, s);
+    cgh_spmv_opts so;
+    so.no_alloc = sv->no_alloc;
+    int rc = cgh_launch_spmv(sv->m, d_x, sv->Ap, nullptr, nullptr, nullptr, s, &so);
     if (rc) return rc;
     if (sv->precond == CGH_PRECOND_JACOBI) {
         if (sv->strict) {
@@ -281,9 +276,8 @@ static int enqueue_iterations(cgh_solver *sv, int count, int time_kernels, bool 
         // serpentine sweeps: each kernel starts where the previous one ended, so the tail of what was just
         // written/read could still be in the 256 MiB Infinity Cache.  Measured null on MI355X (0.4791 vs 0.4797
         // ms/iter, 256^3), so off by default; env CGH_SERPENTINE=1 enables it for experiments.
-        static const int serp = getenv("CGH_SERPENTINE") ? atoi(getenv("CGH_SERPENTINE")) : 0;
-        const int        rev1 = serp ? (host_iter & 1) : 0, rev2 = serp ? !rev1 : 0;
-        g_cgh.sweep_reverse = rev1;
+        const int serp = g_cfg.serpentine;
+        const int rev1 = serp ? (host_iter & 1) : 0, rev2 = serp ? !rev1 : 0;
         const bool timed = time_kernels > 0 && c % time_kernels == 0;  // every time_kernels-th iteration of this call
         if (timed) {
             hipEvent_t a, b;
@@ -294,14 +288,14 @@ static int enqueue_iterations(cgh_solver *sv, int count, int time_kernels, bool 
             CGH_HIP(hipEventRecord(a, s));
         }
         // strict mode with the parallel sums: the SpMV leaves p.Ap per 128-row cell (their binade prediction) if it can
-        g_cgh.cell_sums = sv->strict && sv->precond == CGH_PRECOND_NONE ? cgh_xsum_cellsums(sv->xs) : nullptr;
-        g_cgh.cell_sums_written = false;
-        int rc = cgh_launch_spmv(sv->m, dp, dAp, sv->strict ? nullptr : dA, &gridA, dd, s);
-        const bool pAp_presummed = g_cgh.cell_sums_written;
-        g_cgh.cell_sums = nullptr;
-        g_cgh.cell_sums_written = false;
+        bool          pAp_presummed = false;
+        cgh_spmv_opts so;
+        so.cell_sums = sv->strict && sv->precond == CGH_PRECOND_NONE ? cgh_xsum_cellsums(sv->xs) : nullptr;
+        so.cell_sums_written = &pAp_presummed;
+        so.reverse = rev1;
+        so.no_alloc = sv->no_alloc;
+        int rc = cgh_launch_spmv(sv->m, dp, dAp, sv->strict ? nullptr : dA, &gridA, dd, s, &so);
         if (rc) return rc;
-        g_cgh.sweep_reverse = 0;
         if (timed) CGH_HIP(hipEventRecord(sv->kev.back(), s));
         if (sv->precond == CGH_PRECOND_JACOBI) {
             const double *dg = sv->m->diag;
@@ -322,8 +316,8 @@ static int enqueue_iterations(cgh_solver *sv, int count, int time_kernels, bool 
                                (const double *)dB, vg, dh, iter, tol, dd, rev1, (const double *)nullptr);
         } else {
             // non-temporal loads + x store (3) unless the working set is within twice the Infinity Cache (0): see cgh_fits_llc
-            static const int vv_env = getenv("CGH_VEC_VARIANT") ? atoi(getenv("CGH_VEC_VARIANT")) & 15 : -1;
-            const int        vv = vv_env >= 0 ? vv_env : (sv->m->layout == CGH_LAYOUT_ELL && cgh_fits_llc(sv->m, 2.0) ? 0 : 3);
+            const int vv_env = g_cfg.vec_variant >= 0 ? g_cfg.vec_variant & 15 : -1;
+            const int vv = vv_env >= 0 ? vv_env : (sv->m->layout == CGH_LAYOUT_ELL && cgh_fits_llc(sv->m, 2.0) ? 0 : 3);
 #define CGH_VEC_VAR(V)                                                                                                 \
     case V:                                                                                                            \
         hipLaunchKernelGGL((cg_update_r<0, V>), dim3(vg), dim3(CGH_BLOCK), 0, s, n, dr, (const double *)dAp,       \
@@ -363,8 +357,8 @@ int cgh_solver_iterate(cgh_solver *sv, int count, int time_kernels)
         cgh_set_error("cgh_solver_iterate: count %d exceeds the solver's capacity", count);
         return CGH_EINVAL;
     }
-    const int     use_graphs = getenv("CGH_GRAPH") ? atoi(getenv("CGH_GRAPH")) : 0;
-    const int64_t graph_rows = getenv("CGH_GRAPH_MAX_ROWS") ? atoll(getenv("CGH_GRAPH_MAX_ROWS")) : (1 << 21);
+    const int     use_graphs = g_cfg.graph;
+    const int64_t graph_rows = g_cfg.graph_max_rows;
     if (!use_graphs || time_kernels || count < 4 || sv->n > graph_rows) return enqueue_iterations(sv, count, time_kernels, false);
     hipStream_t    s = g_cgh.stream;
     hipGraphExec_t exec = nullptr;

@@ -16,11 +16,6 @@ struct cgh_context {
     int         num_cu = 256;
     hipStream_t stream = nullptr;       // compute stream: every kernel of the solver
     hipStream_t comm_stream = nullptr;  // halo exchange / collectives (multi-GPU)
-    int         sweep_reverse = 0;      // 1: the next launches walk their arrays from the end (serpentine sweeps)
-    // strict mode: the next SpMV may leave x.y summed per 128-row cell in cell_sums (xsum.hip's binade prediction);
-    // the launcher sets cell_sums_written if the kernel it chose did so
-    double     *cell_sums = nullptr;
-    bool        cell_sums_written = false;
     char        err[512] = {0};
 };
 extern cgh_context g_cgh;
@@ -97,8 +92,28 @@ struct cgh_matrix {
     int      sigma = 0;
 };
 
+// What a caller may ask of ONE SpMV launch beyond y = A x (explicit arguments: nothing about a launch travels through
+// process-wide state, so two solvers may interleave their launches).
+struct cgh_spmv_opts {
+    double *cell_sums = nullptr;         // strict mode: the kernel may leave x.y summed per 128-row cell here (xsum.hip's
+    bool   *cell_sums_written = nullptr; // binade prediction); *cell_sums_written says whether the kernel it chose did
+    int     reverse = 0;                 // 1: walk the rows from the end (serpentine sweeps)
+    bool    no_alloc = false;            // the call must not allocate: an ELL matrix's column dictionary is not built now
+};
+
 // Knobs read from the environment ONCE, in cgh_init (never in a launch path); cgh_config_* setters override them.
 struct cgh_config {
+    int    ell_generic = 0;     // CGH_ELL_GENERIC: runtime-K ELL kernel for every width (tests)
+    int    ell_dict = -1;       // CGH_ELL_DICT: 0 no dictionary-coded columns, 1 / 2 force the byte / packed layout, -1 automatic
+    int    ell_variant = -1;    // CGH_ELL_VARIANT: cache-hint variant of the ELL SpMV, -1 = by working-set size
+    double llc_mb = 224.0;      // CGH_LLC_MB: working sets below this many MiB run without streaming hints
+    int    csr_window = 1024;   // CGH_CSR_WINDOW: entries per row block of the CSR stream kernel (512 | 1024 | 2048)
+    int    csr_exact = 0;       // CGH_CSR_EXACT: every CSR row summed strictly left to right
+    int64_t xsum_min_rows = 4096; // CGH_XSUM_MIN_ROWS: shortest vector taking the order-exact parallel sums (-1 never)
+    int    serpentine = 0;      // CGH_SERPENTINE: alternate the sweep direction of the iteration's kernels
+    int    vec_variant = -1;    // CGH_VEC_VARIANT: cache-hint variant of the vector kernels, -1 = by working-set size
+    int    graph = 0;           // CGH_GRAPH: replay batches of iterations from HIP graphs
+    int64_t graph_max_rows = 1 << 21; // CGH_GRAPH_MAX_ROWS
     int csrb_rpw = 1024;        // CGH_CSRB_RPW: rows per wave-block of the column-blocked CSR (512 | 1024 | 2048)
     int csrb_slab_bits = 17;    // CGH_CSRB_SLAB_BITS: log2 of the columns per slab (2^17 doubles = 1 MiB of x)
     int csrb_wgs_per_cu = 0;    // CGH_CSRB_WGS: workgroups per CU of the column-blocked kernel (0 = what LDS admits)
@@ -127,7 +142,13 @@ static inline int cgh_stream_grid(int64_t tiles, int blocks_per_cu)
 // --------------------------------------------------------------- kernels (host launchers)
 // spmv.hip
 int cgh_launch_spmv(const cgh_matrix *m, const double *x, double *y, double *dot_partials, int *grid_out,
-                    const int *done_flag, hipStream_t s);
+                    const int *done_flag, hipStream_t s, const cgh_spmv_opts *opts = nullptr);
+// spmv_ell.hip: rows [rb, re) (+ [rb2, re2)) of an ELL matrix; x may be longer than n (multi-GPU halo entries follow)
+int cgh_launch_spmv_ell_range(const cgh_matrix *m, const double *x, double *y, double *dot_partials, int *grid_out,
+                              const int *done, hipStream_t s, int64_t rb, int64_t re, const cgh_spmv_opts *opts = nullptr);
+int cgh_launch_spmv_ell_range2(const cgh_matrix *m, const double *x, double *y, double *dot_partials, int *grid_out,
+                               const int *done, hipStream_t s, int64_t rb, int64_t re, int64_t rb2, int64_t re2,
+                               const cgh_spmv_opts *opts = nullptr);
 int cgh_spmv_grid(const cgh_matrix *m);
 void cgh_ell_dict_free(const cgh_matrix *m);
 

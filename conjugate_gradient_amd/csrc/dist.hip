@@ -32,11 +32,6 @@
 #include "dist_kernels.h"
 #include "partition.h"
 
-int cgh_launch_spmv_ell_range(const cgh_matrix *m, const double *x, double *y, double *dot_partials, int *grid_out,
-                              const int *done, hipStream_t s, int64_t rb, int64_t re);
-int cgh_launch_spmv_ell_range2(const cgh_matrix *m, const double *x, double *y, double *dot_partials, int *grid_out,
-                               const int *done, hipStream_t s, int64_t rb, int64_t re, int64_t rb2, int64_t re2);
-
 bool cgh_spmv_ell_halo_capable(const cgh_matrix *m, const double *x, double *y, int64_t rb, int64_t re, int64_t rb2, int64_t re2);
 int cgh_launch_spmv_ell_halo(const cgh_matrix *m, const double *x, double *y, double *dot_partials, int *grid_out,
                              const int *done, hipStream_t s, int64_t rb, int64_t re, int64_t rb2, int64_t re2,

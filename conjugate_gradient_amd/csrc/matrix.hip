@@ -4,7 +4,7 @@
 #include "cgh_internal.h"
 
 int cgh_launch_spmv_ell(const cgh_matrix *m, const double *x, double *y, double *dot_partials, int *grid_out,
-                        const int *done, hipStream_t s);
+                        const int *done, hipStream_t s, const cgh_spmv_opts *opts);
 int cgh_launch_spmv_csr(const cgh_matrix *m, const double *x, double *y, double *dot_partials, int *grid_out,
                         const int *done, hipStream_t s);
 int cgh_launch_spmv_sell(const cgh_matrix *m, const double *x, double *y, double *dot_partials, int *grid_out,
@@ -14,10 +14,11 @@ int cgh_launch_spmv_csrb(const cgh_matrix *m, const double *x, double *y, double
 int cgh_csr_to_ell_download(const cgh_matrix *m, double *ell_vals, int *ell_cols);
 
 int cgh_launch_spmv(const cgh_matrix *m, const double *x, double *y, double *dot_partials, int *grid_out,
-                    const int *done, hipStream_t s)
+                    const int *done, hipStream_t s, const cgh_spmv_opts *opts)
 {
+    if (opts && opts->cell_sums_written) *opts->cell_sums_written = false;  // only the ELL kernels can leave them
     switch (m->layout) {
-    case CGH_LAYOUT_ELL: return cgh_launch_spmv_ell(m, x, y, dot_partials, grid_out, done, s);
+    case CGH_LAYOUT_ELL: return cgh_launch_spmv_ell(m, x, y, dot_partials, grid_out, done, s, opts);
     case CGH_LAYOUT_CSR: return cgh_launch_spmv_csr(m, x, y, dot_partials, grid_out, done, s);
     case CGH_LAYOUT_SELL:
     case CGH_LAYOUT_SELLS: return cgh_launch_spmv_sell(m, x, y, dot_partials, grid_out, done, s);

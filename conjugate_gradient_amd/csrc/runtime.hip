@@ -14,6 +14,32 @@ void cgh_set_error(const char *fmt, ...)
     if (!getenv("CG_HIP_SILENT_ERRORS")) fprintf(stderr, "libcg_hip: %s\n", g_cgh.err);
 }
 
+// The CGH_* knobs (DESIGN.md lists them): read by cgh_init and cgh_config_reload only.
+static void read_env_knobs()
+{
+    auto env_int = [](const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; };
+    g_cfg = cgh_config();
+    g_cfg.ell_generic = env_int("CGH_ELL_GENERIC", g_cfg.ell_generic);
+    g_cfg.ell_dict = env_int("CGH_ELL_DICT", g_cfg.ell_dict);
+    g_cfg.ell_variant = env_int("CGH_ELL_VARIANT", g_cfg.ell_variant);
+    if (getenv("CGH_LLC_MB")) g_cfg.llc_mb = atof(getenv("CGH_LLC_MB"));
+    g_cfg.csr_window = env_int("CGH_CSR_WINDOW", g_cfg.csr_window);
+    if (g_cfg.csr_window != 512 && g_cfg.csr_window != 2048) g_cfg.csr_window = 1024;
+    g_cfg.csr_exact = env_int("CGH_CSR_EXACT", g_cfg.csr_exact);
+    if (getenv("CGH_XSUM_MIN_ROWS")) g_cfg.xsum_min_rows = atoll(getenv("CGH_XSUM_MIN_ROWS"));
+    g_cfg.serpentine = env_int("CGH_SERPENTINE", g_cfg.serpentine);
+    g_cfg.vec_variant = env_int("CGH_VEC_VARIANT", g_cfg.vec_variant);
+    g_cfg.graph = env_int("CGH_GRAPH", g_cfg.graph);
+    if (getenv("CGH_GRAPH_MAX_ROWS")) g_cfg.graph_max_rows = atoll(getenv("CGH_GRAPH_MAX_ROWS"));
+    g_cfg.csrb_rpw = env_int("CGH_CSRB_RPW", g_cfg.csrb_rpw);
+    g_cfg.csrb_slab_bits = env_int("CGH_CSRB_SLAB_BITS", g_cfg.csrb_slab_bits);
+    g_cfg.csrb_wgs_per_cu = env_int("CGH_CSRB_WGS", g_cfg.csrb_wgs_per_cu);
+    g_cfg.csrb_window = env_int("CGH_CSRB_WINDOW", g_cfg.csrb_window);
+    g_cfg.csrb_quorum_div = env_int("CGH_CSRB_QUORUM", g_cfg.csrb_quorum_div);
+    g_cfg.csrb_lds_atomics = env_int("CGH_CSRB_LDS_ATOMICS", g_cfg.csrb_lds_atomics);
+    g_cfg.sell_sigma = env_int("CGH_SELL_SIGMA", g_cfg.sell_sigma);
+}
+
 extern "C" {
 
 const char *cgh_last_error(void) { return g_cgh.err; }
@@ -51,16 +77,7 @@ int cgh_init(int device)
         return CGH_ENODEV;
     }
     g_cgh.num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    // knobs: the environment is read here, once, never in a launch path
-    auto env_int = [](const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; };
-    g_cfg = cgh_config();
-    g_cfg.csrb_rpw = env_int("CGH_CSRB_RPW", g_cfg.csrb_rpw);
-    g_cfg.csrb_slab_bits = env_int("CGH_CSRB_SLAB_BITS", g_cfg.csrb_slab_bits);
-    g_cfg.csrb_wgs_per_cu = env_int("CGH_CSRB_WGS", g_cfg.csrb_wgs_per_cu);
-    g_cfg.csrb_window = env_int("CGH_CSRB_WINDOW", g_cfg.csrb_window);
-    g_cfg.csrb_quorum_div = env_int("CGH_CSRB_QUORUM", g_cfg.csrb_quorum_div);
-    g_cfg.csrb_lds_atomics = env_int("CGH_CSRB_LDS_ATOMICS", g_cfg.csrb_lds_atomics);
-    g_cfg.sell_sigma = env_int("CGH_SELL_SIGMA", g_cfg.sell_sigma);
+    read_env_knobs();  // the environment is read here, once, never in a launch path
     CGH_HIP(hipStreamCreateWithFlags(&g_cgh.stream, hipStreamNonBlocking));
     CGH_HIP(hipStreamCreateWithFlags(&g_cgh.comm_stream, hipStreamNonBlocking));
     g_cgh.device = device;
@@ -77,6 +94,14 @@ void cgh_shutdown(void)
     g_cgh.stream = g_cgh.comm_stream = nullptr;
     g_cgh.ready = false;
     g_cgh.device = -1;
+}
+
+// Re-read the CGH_* environment knobs (cgh_init reads them once; tests that change the environment between two solves call this).
+int cgh_config_reload(void)
+{
+    CGH_REQUIRE_READY(CGH_ENODEV);
+    read_env_knobs();
+    return CGH_OK;
 }
 
 int cgh_config_sell_sigma(int sigma_rows)

@@ -26,17 +26,9 @@ namespace {
 
 // entries per row-block window (a block's rows start in one window and the last may run one window over, so the LDS
 // stage holds 2*window products): 1024 -> 16 KB of LDS per workgroup, 8 workgroups per CU
-constexpr int CSR_WINDOW_DEFAULT = 1024;
 constexpr int CSR_WAVE_ROW = 64;             // rows longer than this are summed by a wave
 
-int csr_window()
-{
-    static const int w = [] {
-        const int v = getenv("CGH_CSR_WINDOW") ? atoi(getenv("CGH_CSR_WINDOW")) : CSR_WINDOW_DEFAULT;
-        return (v == 512 || v == 1024 || v == 2048) ? v : CSR_WINDOW_DEFAULT;
-    }();
-    return w;
-}
+int csr_window() { return g_cfg.csr_window; }
 
 __global__ __launch_bounds__(256) void flag_row_blocks(int64_t n, const int64_t *__restrict__ row_ptr, int *__restrict__ flag, int CSR_WINDOW)
 {
@@ -224,7 +216,7 @@ static void launch_csr(const cgh_matrix *m, const double *x, double *y, double *
 int cgh_launch_spmv_csr(const cgh_matrix *m, const double *x, double *y, double *dot_partials, int *grid_out,
                         const int *done, hipStream_t s)
 {
-    const int     exact = m->exact_rows || (getenv("CGH_CSR_EXACT") ? atoi(getenv("CGH_CSR_EXACT")) : 0);
+    const int     exact = m->exact_rows || g_cfg.csr_exact;
     const int64_t nb = m->bin_start[0];
     const int     w = (int)m->bin_start[1];   // the window the row blocks were built for
     const int     grid = cgh_stream_grid(nb, w <= 1024 ? 8 : 5);

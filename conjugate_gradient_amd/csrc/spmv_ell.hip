@@ -241,15 +241,14 @@ inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 
 template <int DOT, int VAR, int DICT = 0, int HALO = 0>
 void launch_r2(int K, int grid, hipStream_t s, int64_t n, const double *diag, const double *vals, const void *cols,
                const int *off_tab, const double *x, double *y, double *partials, const int *done, int64_t rb, int64_t re,
-               int64_t rb2, int64_t re2, cgh_ll_halo hl = cgh_ll_halo{nullptr, 0, 0, 0u, nullptr})
+               int64_t rb2, int64_t re2, int reverse = 0, cgh_ll_halo hl = cgh_ll_halo{nullptr, 0, 0, 0u, nullptr})
 {
 #define CGH_ELL_CASE(KK)                                                                                       \
     case KK:                                                                                                   \
         hipLaunchKernelGGL((spmv_ell_r2<KK, DOT, VAR, DICT, HALO>), dim3(grid), dim3(CGH_BLOCK), 0, s, n, K, diag, vals, cols, \
-                           off_tab, x, y, partials, done, g_cgh.sweep_reverse, rb, re, rb2, re2, hl);                 \
+                           off_tab, x, y, partials, done, reverse, rb, re, rb2, re2, hl);                             \
         break;
-    static const int generic = getenv("CGH_ELL_GENERIC") ? atoi(getenv("CGH_ELL_GENERIC")) : 0;
-    switch (generic ? -1 : K) {
+    switch (g_cfg.ell_generic ? -1 : K) {
         CGH_ELL_CASE(1)
         CGH_ELL_CASE(2)
         CGH_ELL_CASE(3)
@@ -262,7 +261,7 @@ void launch_r2(int K, int grid, hipStream_t s, int64_t n, const double *diag, co
         CGH_ELL_CASE(26)
     default:
         hipLaunchKernelGGL((spmv_ell_r2<0, DOT, VAR, DICT, HALO>), dim3(grid), dim3(CGH_BLOCK), 0, s, n, K, diag, vals, cols, off_tab,
-                           x, y, partials, done, g_cgh.sweep_reverse, rb, re, rb2, re2, hl);
+                           x, y, partials, done, reverse, rb, re, rb2, re2, hl);
     }
 #undef CGH_ELL_CASE
 }
@@ -378,7 +377,7 @@ __global__ __launch_bounds__(256) void dict_encode_packed(int64_t n, int K, cons
 void ell_dict_try_build(const cgh_matrix *m, hipStream_t s)
 {
     m->dict_state = 2;
-    const int     enabled = getenv("CGH_ELL_DICT") ? atoi(getenv("CGH_ELL_DICT")) : 1;  // read per matrix (tests toggle it)
+    const int     enabled = g_cfg.ell_dict < 0 ? 1 : g_cfg.ell_dict;
     const int64_t total = m->n * (int64_t)m->K;
     if (!enabled || m->K <= 0 || total < 2) return;
     int *work = (int *)cgh_alloc(sizeof(int) * (DICT_SLOTS + 2));
@@ -402,7 +401,7 @@ void ell_dict_try_build(const cgh_matrix *m, hipStream_t s)
     offs.resize(256, 0);
     // narrow rows: one byte per entry, slot-major; wide rows (more load instructions than bytes are worth): 4 slots
     // of a row per 32-bit word.  CGH_ELL_DICT=1 / 2 forces a layout.
-    const int mode = enabled == 2 ? 2 : (enabled == 1 && getenv("CGH_ELL_DICT") ? 1 : (m->K > 8 ? 2 : 1));
+    const int mode = enabled == 2 ? 2 : (g_cfg.ell_dict == 1 ? 1 : (m->K > 8 ? 2 : 1));
     const size_t code_bytes = mode == 2 ? (size_t)((m->K + 3) / 4) * (size_t)m->n * 4 : (size_t)total;
     m->off_tab = (int *)cgh_alloc(sizeof(int) * 256);
     m->cols8 = (unsigned char *)cgh_alloc(code_bytes);
@@ -456,7 +455,7 @@ static inline bool ell_vector_path(const cgh_matrix *m, const double *x, const d
 // (106.9 -> 103.1) and the SpMV loses; at 8.4M everything loses (202.9 -> 233.2).
 bool cgh_fits_llc(const cgh_matrix *m, double times)
 {
-    static const double limit = (getenv("CGH_LLC_MB") ? atof(getenv("CGH_LLC_MB")) : 224.0) * 1048576.0;
+    const double limit = g_cfg.llc_mb * 1048576.0;
     const double per_entry = m->dict_state == 1 ? 9.0 : 12.0;
     return (double)m->stored * per_entry + (double)m->n * 8.0 * 5.0 <= limit * times;
 }
@@ -472,14 +471,11 @@ static int ell_grid_rows(int64_t rows)
 
 int cgh_ell_grid(const cgh_matrix *m) { return ell_grid_rows(m->n); }
 
-int cgh_launch_spmv_ell_range2(const cgh_matrix *m, const double *x, double *y, double *dot_partials, int *grid_out,
-                               const int *done, hipStream_t s, int64_t rb, int64_t re, int64_t rb2, int64_t re2);
-
 // y[rb:re) = (A x)[rb:re).  The slot stride is m->n; x may be longer than n (multi-GPU: halo entries follow the owned ones).
 int cgh_launch_spmv_ell_range(const cgh_matrix *m, const double *x, double *y, double *dot_partials, int *grid_out,
-                              const int *done, hipStream_t s, int64_t rb, int64_t re)
+                              const int *done, hipStream_t s, int64_t rb, int64_t re, const cgh_spmv_opts *opts)
 {
-    return cgh_launch_spmv_ell_range2(m, x, y, dot_partials, grid_out, done, s, rb, re, 0, 0);
+    return cgh_launch_spmv_ell_range2(m, x, y, dot_partials, grid_out, done, s, rb, re, 0, 0, opts);
 }
 
 bool cgh_spmv_ell_halo_capable(const cgh_matrix *m, const double *x, double *y, int64_t rb, int64_t re, int64_t rb2, int64_t re2)
@@ -489,8 +485,12 @@ bool cgh_spmv_ell_halo_capable(const cgh_matrix *m, const double *x, double *y, 
 
 // Two row ranges in one launch (second may be empty).
 int cgh_launch_spmv_ell_range2(const cgh_matrix *m, const double *x, double *y, double *dot_partials, int *grid_out,
-                               const int *done, hipStream_t s, int64_t rb, int64_t re, int64_t rb2, int64_t re2)
+                               const int *done, hipStream_t s, int64_t rb, int64_t re, int64_t rb2, int64_t re2,
+                               const cgh_spmv_opts *opts)
 {
+    const int  rev = opts ? opts->reverse : 0;
+    double    *cell_sums = opts ? opts->cell_sums : nullptr;
+    if (opts && opts->cell_sums_written) *opts->cell_sums_written = false;
     if (re < rb) re = rb;
     if (re2 < rb2) re2 = rb2;
     const int64_t rows = (re - rb) + (re2 - rb2);
@@ -500,30 +500,30 @@ int cgh_launch_spmv_ell_range2(const cgh_matrix *m, const double *x, double *y, 
     if (!(ell_vector_path(m, x, y) && rb % 2 == 0 && re % 2 == 0 && rb2 % 2 == 0 && re2 % 2 == 0) && re2 > rb2) {
         // scalar path: one launch per range
         int g1 = 0, g2 = 0;
-        int rc = cgh_launch_spmv_ell_range2(m, x, y, dot_partials, &g1, done, s, rb, re, 0, 0);
+        int rc = cgh_launch_spmv_ell_range2(m, x, y, dot_partials, &g1, done, s, rb, re, 0, 0, opts);
         if (rc) return rc;
-        rc = cgh_launch_spmv_ell_range2(m, x, y, dot_partials ? dot_partials + g1 : nullptr, &g2, done, s, rb2, re2, 0, 0);
+        rc = cgh_launch_spmv_ell_range2(m, x, y, dot_partials ? dot_partials + g1 : nullptr, &g2, done, s, rb2, re2, 0, 0, opts);
         if (grid_out) *grid_out = g1 + g2;
         return rc;
     }
     if (ell_vector_path(m, x, y) && rb % 2 == 0 && re % 2 == 0 && rb2 % 2 == 0 && re2 % 2 == 0) {
-        if (m->dict_state == 0) {
+        if (m->dict_state == 0 && !(opts && opts->no_alloc)) {
             hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
             (void)hipStreamIsCapturing(s, &cap);
             if (cap == hipStreamCaptureStatusNone) ell_dict_try_build(m, s);
         }
         // strict mode's per-cell sums of x.y instead of per-workgroup partials
-        if (g_cgh.cell_sums != nullptr && dot_partials == nullptr && rb == 0 && re == m->n && re2 <= rb2 && m->n % 128 == 0) {
+        if (cell_sums != nullptr && dot_partials == nullptr && rb == 0 && re == m->n && re2 <= rb2 && m->n % 128 == 0) {
             if (m->dict_state == 1 && m->dict_mode == 2)
-                launch_r2<2, VAR_DEFAULT, 2>(m->K, grid, s, m->n, m->diag, m->vals, m->cols8, m->off_tab, x, y, g_cgh.cell_sums, done,
-                                             rb, re, rb2, re2);
+                launch_r2<2, VAR_DEFAULT, 2>(m->K, grid, s, m->n, m->diag, m->vals, m->cols8, m->off_tab, x, y, cell_sums, done,
+                                             rb, re, rb2, re2, rev);
             else if (m->dict_state == 1)
-                launch_r2<2, VAR_DEFAULT, 1>(m->K, grid, s, m->n, m->diag, m->vals, m->cols8, m->off_tab, x, y, g_cgh.cell_sums, done,
-                                             rb, re, rb2, re2);
+                launch_r2<2, VAR_DEFAULT, 1>(m->K, grid, s, m->n, m->diag, m->vals, m->cols8, m->off_tab, x, y, cell_sums, done,
+                                             rb, re, rb2, re2, rev);
             else
-                launch_r2<2, VAR_DEFAULT, 0>(m->K, grid, s, m->n, m->diag, m->vals, m->cols, nullptr, x, y, g_cgh.cell_sums, done, rb,
-                                             re, rb2, re2);
-            g_cgh.cell_sums_written = true;
+                launch_r2<2, VAR_DEFAULT, 0>(m->K, grid, s, m->n, m->diag, m->vals, m->cols, nullptr, x, y, cell_sums, done, rb,
+                                             re, rb2, re2, rev);
+            if (opts->cell_sums_written) *opts->cell_sums_written = true;
             CGH_HIP(hipGetLastError());
             return CGH_OK;
         }
@@ -531,15 +531,15 @@ int cgh_launch_spmv_ell_range2(const cgh_matrix *m, const double *x, double *y, 
             // Variant: 11 = non-temporal matrix loads and y store (the matrix streams through once, x stays in L2); 1 = plain
             // loads and stores, for working sets the 256 MiB Infinity Cache can hold from one kernel to the next (there the
             // hints cost 4-8 % of an iteration: tools/quick_mall.py); CGH_ELL_VARIANT=1|3|11 overrides (3: NT loads only)
-            static const int forced = getenv("CGH_ELL_VARIANT") ? atoi(getenv("CGH_ELL_VARIANT")) : -1;
-            const int        dvar = (forced == 1 || forced == 3 || forced == 11) ? forced : (cgh_fits_llc(m, 1.0) ? 1 : VAR_DEFAULT);
+            const int forced = g_cfg.ell_variant;
+            const int dvar = (forced == 1 || forced == 3 || forced == 11) ? forced : (cgh_fits_llc(m, 1.0) ? 1 : VAR_DEFAULT);
 #define CGH_ELL_DICT_LAUNCH(V, MODE)                                                                                       \
     if (dot_partials)                                                                                                      \
         launch_r2<true, V, MODE>(m->K, grid, s, m->n, m->diag, m->vals, m->cols8, m->off_tab, x, y, dot_partials, done, rb, re, \
-                                 rb2, re2);                                                                                \
+                                 rb2, re2, rev);                                                                           \
     else                                                                                                                   \
         launch_r2<false, V, MODE>(m->K, grid, s, m->n, m->diag, m->vals, m->cols8, m->off_tab, x, y, nullptr, done, rb, re, rb2, \
-                                  re2);
+                                  re2, rev);
             if (m->dict_mode == 2) {
                 if (dvar == 3) {
                     CGH_ELL_DICT_LAUNCH(3, 2)
@@ -559,17 +559,15 @@ int cgh_launch_spmv_ell_range2(const cgh_matrix *m, const double *x, double *y, 
             CGH_HIP(hipGetLastError());
             return CGH_OK;
         }
-        static const int var_env = [] {
-            const int v = getenv("CGH_ELL_VARIANT") ? atoi(getenv("CGH_ELL_VARIANT")) : -1;
-            return (v == 0 || v == 1 || v == 2 || v == 3 || v == 7 || v == 11) ? v : -1;
-        }();
+        const int v_cfg = g_cfg.ell_variant;
+        const int var_env = (v_cfg == 0 || v_cfg == 1 || v_cfg == 2 || v_cfg == 3 || v_cfg == 7 || v_cfg == 11) ? v_cfg : -1;
         const int var = var_env >= 0 ? var_env : (cgh_fits_llc(m, 1.0) ? 1 : VAR_DEFAULT);
 #define CGH_ELL_VAR(V)                                                                                                  \
     case V:                                                                                                             \
         if (dot_partials)                                                                                               \
-            launch_r2<true, V>(m->K, grid, s, m->n, m->diag, m->vals, m->cols, nullptr, x, y, dot_partials, done, rb, re, rb2, re2); \
+            launch_r2<true, V>(m->K, grid, s, m->n, m->diag, m->vals, m->cols, nullptr, x, y, dot_partials, done, rb, re, rb2, re2, rev); \
         else                                                                                                            \
-            launch_r2<false, V>(m->K, grid, s, m->n, m->diag, m->vals, m->cols, nullptr, x, y, nullptr, done, rb, re, rb2, re2); \
+            launch_r2<false, V>(m->K, grid, s, m->n, m->diag, m->vals, m->cols, nullptr, x, y, nullptr, done, rb, re, rb2, re2, rev); \
         break;
         switch (var) {
             CGH_ELL_VAR(0)
@@ -610,12 +608,12 @@ int cgh_launch_spmv_ell_halo(const cgh_matrix *m, const double *x, double *y, do
 #define CGH_ELL_HALO_LAUNCH(V)                                                                                                 \
     if (m->dict_state == 1 && m->dict_mode == 2)                                                                               \
         launch_r2<1, V, 2, 1>(m->K, grid, s, m->n, m->diag, m->vals, m->cols8, m->off_tab, x, y, dot_partials, done, rb, re, rb2, re2, \
-                              *hl);                                                                                            \
+                              0, *hl);                                                                                            \
     else if (m->dict_state == 1)                                                                                               \
         launch_r2<1, V, 1, 1>(m->K, grid, s, m->n, m->diag, m->vals, m->cols8, m->off_tab, x, y, dot_partials, done, rb, re, rb2, re2, \
-                              *hl);                                                                                            \
+                              0, *hl);                                                                                            \
     else                                                                                                                       \
-        launch_r2<1, V, 0, 1>(m->K, grid, s, m->n, m->diag, m->vals, m->cols, nullptr, x, y, dot_partials, done, rb, re, rb2, re2, *hl);
+        launch_r2<1, V, 0, 1>(m->K, grid, s, m->n, m->diag, m->vals, m->cols, nullptr, x, y, dot_partials, done, rb, re, rb2, re2, 0, *hl);
     if (cgh_fits_llc(m, 1.0)) {
         CGH_ELL_HALO_LAUNCH(1)
     } else {
@@ -627,11 +625,12 @@ int cgh_launch_spmv_ell_halo(const cgh_matrix *m, const double *x, double *y, do
 }
 
 int cgh_launch_spmv_ell(const cgh_matrix *m, const double *x, double *y, double *dot_partials, int *grid_out,
-                        const int *done, hipStream_t s)
+                        const int *done, hipStream_t s, const cgh_spmv_opts *opts)
 {
+    if (opts && opts->cell_sums_written) *opts->cell_sums_written = false;
     if (m->n == 0) {
         if (grid_out) *grid_out = 0;
         return CGH_OK;
     }
-    return cgh_launch_spmv_ell_range(m, x, y, dot_partials, grid_out, done, s, 0, m->n);
+    return cgh_launch_spmv_ell_range(m, x, y, dot_partials, grid_out, done, s, 0, m->n, opts);
 }

@@ -104,6 +104,9 @@ int     cgh_matrix_set_exact_rows(cgh_matrix *m, int exact);
  * Sorting window (rows) of the sigma-sorted sliced ELL. */
 int     cgh_config_csrb(int rows_per_wave_block, int slab_bits, int wgs_per_cu, int window, int quorum_div, int lds_atomics);
 int     cgh_config_sell_sigma(int sigma_rows);
+/* The CGH_* environment knobs (DESIGN.md lists them) are read ONCE, by cgh_init, never in a launch path; a host that
+ * changes the environment afterwards (tests do) calls this to have them read again. */
+int     cgh_config_reload(void);
 /* Host-side planner of the column-blocked CSR (no GPU needed; exported for tests): deals nseg segments of the given
  * weights (entries) to ceil(nseg/spb) blocks of at most spb segments each, heaviest first to the lightest block with a
  * free slot.  seg_block[s], seg_slot[s] receive the placement.  Returns the number of blocks. */

@@ -33,3 +33,10 @@ def same_bits_nan(a, b):
     a = np.asarray(a); b = np.asarray(b)
     return (a.shape == b.shape and np.array_equal(np.isnan(a), np.isnan(b))
             and np.array_equal(bits(np.nan_to_num(a)), bits(np.nan_to_num(b))))
+
+
+def setknob(monkeypatch, name, value):
+    """set a CGH_* environment knob for this test and have the library read its knobs again"""
+    import conjugate_gradient_amd as cga
+    monkeypatch.setenv(name, str(value))
+    cga.check(cga.lib().cgh_config_reload(), "cgh_config_reload")

@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 import oracle_lib as O
-from gpu_common import GOLDENS, bits, golden, inputs, same_bits_nan
+from gpu_common import setknob, GOLDENS, bits, golden, inputs, same_bits_nan
 
 pytestmark = pytest.mark.gpu
 
@@ -173,9 +173,9 @@ def test_graph_replay_matches_eager(cga, strict, monkeypatch):
     n, K = s["n"], int(g["K_full"])
     A = cga.Matrix.from_ell(n, K, s["diag"], g["ell_full_vals"], g["ell_full_cols"])
     b = cga.DeviceVector.from_host(s["source"]); x = cga.DeviceVector(n); x2 = cga.DeviceVector(n)
-    monkeypatch.setenv("CGH_GRAPH", "0")
+    setknob(monkeypatch, "CGH_GRAPH", "0")
     rep, hist = cga.cg_solve(A, b, x, max_iter=1000, tol=1e-6, strict=strict, check_every=32)
-    monkeypatch.setenv("CGH_GRAPH", "1")
+    setknob(monkeypatch, "CGH_GRAPH", "1")
     rep2, hist2 = cga.cg_solve(A, b, x2, max_iter=1000, tol=1e-6, strict=strict, check_every=32)
     assert rep2.ret == rep.ret and same_bits_nan(hist2, hist)
     assert np.array_equal(bits(x2.to_host()), bits(x.to_host()))

@@ -6,7 +6,7 @@ import pytest
 
 import foamio
 import oracle_lib as O
-from gpu_common import GOLDENS, bits, golden, inputs, same_bits_nan
+from gpu_common import setknob, GOLDENS, bits, golden, inputs, same_bits_nan
 
 pytestmark = pytest.mark.gpu
 LAYOUTS = [0, 1, 2]
@@ -150,7 +150,7 @@ def test_dictionary_coded_columns_same_bits(cga, monkeypatch, case):
     x = cga.DeviceVector.from_host(xh); y = cga.DeviceVector(n)
     out = {}
     for flag in ("0", "1", "2"):      # int32 columns / one byte per entry / 4 slots of a row per 32-bit word
-        monkeypatch.setenv("CGH_ELL_DICT", flag)
+        setknob(monkeypatch, "CGH_ELL_DICT", flag)
         A = cga.Matrix.from_coo(n, s["diag"], s["upper"], s["rows"], s["cols"], cga.LAYOUT_ELL)
         assert A.dict_offsets == -1
         A.spmv(x, y)
@@ -163,3 +163,39 @@ def test_dictionary_coded_columns_same_bits(cga, monkeypatch, case):
         assert 0 < out["1"][1] <= 255 and out["2"][1] == out["1"][1]
     elif case == "unstructured":
         assert out["1"][1] == 0 and out["2"][1] == 0
+
+
+def test_two_solvers_interleaved_reproduce_their_solo_bits(cga):
+    """Nothing about a launch travels through process-wide state (cgh_spmv_opts): a strict and a throughput-mode solver on
+    the SAME matrix, their iteration batches interleaved, give exactly the histories and solutions each gives alone
+    (the strict one bit-identical to the reference's golden trajectory).  The strict one leaves per-cell sums of p.Ap for
+    its order-exact dot (n is a multiple of 128 and above the parallel-sum threshold), the other per-workgroup partials."""
+    s, g = inputs("cylinder_8000"), golden("cylinder_8000")
+    n, K = s["n"], int(g["K_full"])
+    A = cga.Matrix.from_ell(n, K, s["diag"], g["ell_full_vals"], g["ell_full_cols"])
+    b = cga.DeviceVector.from_host(s["source"])
+    cap = int(g["max_iter"])
+    solo = {}
+    for strict in (1, 0):
+        x = cga.DeviceVector(n)
+        sv = cga.Solver(A, cap)
+        sv.start(b, x, tol=float(g["tol"]), strict=strict)
+        for _ in range(20):
+            sv.iterate(30)
+        done, queued = sv.poll()
+        assert 0 < done < queued
+        solo[strict] = (done, sv.history(0, done + 1), x.to_host())   # entries after the converging iteration are not written
+        sv.free()
+    xs = {1: cga.DeviceVector(n), 0: cga.DeviceVector(n)}
+    svs = {1: cga.Solver(A, cap), 0: cga.Solver(A, cap)}
+    for strict in (1, 0):
+        svs[strict].start(b, xs[strict], tol=float(g["tol"]), strict=strict)
+    for k in range(20):                                   # interleave: 7 + 23 iterations of one, 30 of the other
+        svs[1].iterate(7); svs[0].iterate(30); svs[1].iterate(23)
+    for strict in (1, 0):
+        done, queued = svs[strict].poll()
+        assert done == solo[strict][0] and done > 0
+        assert same_bits_nan(svs[strict].history(0, done + 1), solo[strict][1])
+        assert np.array_equal(bits(xs[strict].to_host()), bits(solo[strict][2]))
+        svs[strict].free()
+    assert solo[1][0] + 1 == int(g["cg_ret"][4]) and same_bits_nan(solo[1][1], g["traj"])

@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 import oracle_lib as O
-from gpu_common import bits, golden, inputs, same_bits_nan
+from gpu_common import setknob, bits, golden, inputs, same_bits_nan
 from test_xsum_model import cases
 
 pytestmark = pytest.mark.gpu
@@ -30,7 +30,7 @@ def eq(a, b):
 @pytest.mark.parametrize("name,t", [c for c in cases() if c[1].size > 0], ids=[c[0] for c in cases() if c[1].size > 0])
 def test_device_sum_equals_sequential(cga, monkeypatch, name, t):
     """sum t[i] as dot(t, 1) and, for non-negative data, as l1norm(t): forced through the parallel path at every size"""
-    monkeypatch.setenv("CGH_XSUM_MIN_ROWS", "0")
+    setknob(monkeypatch, "CGH_XSUM_MIN_ROWS", "0")
     t = np.ascontiguousarray(t, dtype=np.float64)
     n = t.size
     dt = cga.DeviceVector.from_host(t); d1 = cga.DeviceVector.from_host(np.ones(n))
@@ -59,7 +59,7 @@ def test_device_dot_products(cga, monkeypatch):
 @pytest.mark.parametrize("tag", ["cylinder_2000", "cylinder_32k", "poisson27_12x10x8"])
 def test_strict_cg_through_parallel_sums(cga, monkeypatch, tag):
     """the golden trajectories again, with every strict sum forced through xsum.hip instead of the one-lane kernel"""
-    monkeypatch.setenv("CGH_XSUM_MIN_ROWS", "0")
+    setknob(monkeypatch, "CGH_XSUM_MIN_ROWS", "0")
     s, g = inputs(tag), golden(tag)
     n, K = s["n"], int(g["K_full"])
     A = cga.Matrix.from_ell(n, K, s["diag"], g["ell_full_vals"], g["ell_full_cols"])
@@ -117,7 +117,7 @@ def test_full_size_256cubed_strict_bit_exact(cga):
 
 def test_random_trials_device(cga, monkeypatch):
     """random lengths / scales / sign mixes, both the flat (few cells) and the grouped driver"""
-    monkeypatch.setenv("CGH_XSUM_MIN_ROWS", "0")
+    setknob(monkeypatch, "CGH_XSUM_MIN_ROWS", "0")
     rng = np.random.default_rng(2024)
     for trial in range(120):
         n = int(rng.integers(1, 60000)) if trial % 6 else int(rng.integers(530000, 1200000))
@@ -162,9 +162,9 @@ def test_jacobi_graph_replay_matches_eager(cga, monkeypatch):
     n = nx * ny * nz
     b = cga.DeviceVector(n); x = cga.DeviceVector(n); x2 = cga.DeviceVector(n)
     A = cga.Matrix.poisson(nx, ny, nz, 27, 0x5EED0001, cga.LAYOUT_ELL, b)
-    monkeypatch.setenv("CGH_GRAPH", "0")
+    setknob(monkeypatch, "CGH_GRAPH", "0")
     rep, hist = cga.cg_solve(A, b, x, max_iter=300, tol=1e-8, strict=0, precond=1, check_every=16)
-    monkeypatch.setenv("CGH_GRAPH", "1")
+    setknob(monkeypatch, "CGH_GRAPH", "1")
     rep2, hist2 = cga.cg_solve(A, b, x2, max_iter=300, tol=1e-8, strict=0, precond=1, check_every=16)
     assert rep.ret > 0 and rep2.ret == rep.ret and same_bits_nan(hist2, hist)
     assert np.array_equal(bits(x2.to_host()), bits(x.to_host()))

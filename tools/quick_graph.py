@@ -15,6 +15,7 @@ for shape in ((40, 40, 20), (400, 320, 1), (128, 128, 64), (128, 128, 128), (256
     res = {}
     for g in ("0", "1"):
         os.environ["CGH_GRAPH"] = g
+        cga.check(cga.lib().cgh_config_reload())   # the knobs are read at cgh_init / on request only
         sv = cga.Solver(A, 1300)
         sv.start(b, x, tol=-1.0, strict=0)
         sv.iterate(200, 0)                      # (instantiates the 200-iteration graph)
