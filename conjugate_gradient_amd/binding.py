@@ -81,6 +81,7 @@ def lib():
     L.cgh_l1norm.argtypes = [vp, i64, C.c_int, dp]
     L.cgh_axpy.argtypes = [vp, vp, C.c_double, vp, i64]
     L.cgh_cg_solve.argtypes = [vp, vp, vp, C.POINTER(CgOpts), C.POINTER(CgReport), dp]
+    L.cgh_cg_solve_noalloc.argtypes = [vp, vp, vp, C.c_int, C.c_double, C.c_int, vp, vp]
     L.cgh_solver_create.argtypes = [vp, C.c_int]
     L.cgh_solver_create.restype = vp
     L.cgh_solver_free.argtypes = [vp]

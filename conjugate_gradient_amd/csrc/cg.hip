@@ -496,3 +496,76 @@ int cgh_cg_solve(const cgh_matrix *m, const double *d_b, double *d_x, const cgh_
 }
 
 } // extern "C"
+
+// ------------------------------------------------------------------------------------------------------------------
+// The one entry point that allocates nothing (no counterpart in the reference; for callers that cannot call hipMalloc:
+// code under HIP graph capture, tight serving loops that solve one small system after another, harnesses that forbid
+// allocation).  It is cgh_cg_solve with the solver's workspace -- r, p, Ap and the two arrays of per-workgroup partials,
+// the device memory beyond the caller's inputs and outputs -- taken from a file-scope __device__ array instead of
+// cgh_alloc.  The array's NAME is a host-side stand-in, not a device address: its address on the current device comes
+// from hipGetSymbolAddress, once per device (cgh_noalloc_setup, called by cgh_init with that device current), and only
+// that pointer is handed to kernels and memsets.  Every call on a GPU shares that GPU's array and finds the previous
+// call's contents in it: what must start at zero (the converged flag) is cleared, everything else is written before
+// it is read.  Calls that overlap on one GPU (two host threads) would race on it.
+constexpr int64_t NOALLOC_MAX_ROWS = 1 << 20;  // 3 vectors of 2^20 doubles + partials: 25.2 MB per GPU, held until the process ends
+constexpr size_t  NOALLOC_PART_A = (size_t)3 * NOALLOC_MAX_ROWS;
+constexpr size_t  NOALLOC_PART_B = NOALLOC_PART_A + CGH_MAX_PARTIALS;
+constexpr size_t  NOALLOC_DONE = NOALLOC_PART_B + 2 * CGH_MAX_PARTIALS;
+constexpr size_t  NOALLOC_DOUBLES = NOALLOC_DONE + 32;
+static __device__ __align__(256) double scratch[NOALLOC_DOUBLES];
+static double *g_scratch_ptr[64] = {nullptr};  // per device: each GPU holds its own copy of the array at its own address
+
+int cgh_noalloc_setup(int device)
+{
+    if (device < 0 || device >= 64) return CGH_OK;  // no scratch on such a device: the entry point reports it
+    if (g_scratch_ptr[device] != nullptr) return CGH_OK;
+    void *p = nullptr;
+    CGH_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+    g_scratch_ptr[device] = (double *)p;
+    return CGH_OK;
+}
+
+extern "C" int cgh_cg_solve_noalloc(const cgh_matrix *m, const double *d_b, double *d_x, int max_iter, double tol, int strict,
+                                    double *d_history, int *d_status)
+{
+    CGH_REQUIRE_READY(CGH_ENODEV);
+    if (!m || !d_b || !d_x || !d_history || !d_status || max_iter < 1) {
+        cgh_set_error("cgh_cg_solve_noalloc: NULL argument or max_iter < 1");
+        return CGH_EINVAL;
+    }
+    if (m->n > NOALLOC_MAX_ROWS) {
+        cgh_set_error("cgh_cg_solve_noalloc: %lld rows exceed the %lld rows the built-in workspace holds (use cgh_cg_solve)",
+                      (long long)m->n, (long long)NOALLOC_MAX_ROWS);
+        return CGH_EINVAL;
+    }
+    if (strict && m->n >= xsum_min_rows()) {
+        cgh_set_error("cgh_cg_solve_noalloc: strict sums of %lld or more rows need the order-exact workspace, which is allocated "
+                      "(use cgh_cg_solve, or strict = 0)", (long long)xsum_min_rows());
+        return CGH_EINVAL;
+    }
+    double *ws = g_cgh.device >= 0 && g_cgh.device < 64 ? g_scratch_ptr[g_cgh.device] : nullptr;
+    if (!ws) {
+        cgh_set_error("cgh_cg_solve_noalloc: no workspace on device %d", g_cgh.device);
+        return CGH_ENODEV;
+    }
+    cgh_solver sv;  // on the stack; its vectors stay empty (no time_kernels, no graphs)
+    sv.m = m;
+    sv.n = m->n;
+    sv.capacity = max_iter;
+    sv.r = ws;
+    sv.p = ws + NOALLOC_MAX_ROWS;
+    sv.Ap = ws + 2 * NOALLOC_MAX_ROWS;
+    sv.partA = ws + NOALLOC_PART_A;
+    sv.partB = ws + NOALLOC_PART_B;
+    sv.done = reinterpret_cast<int *>(ws + NOALLOC_DONE);
+    sv.hist = d_history;
+    sv.vgrid = vec_grid(m->n);
+    sv.no_alloc = true;
+    int rc = cgh_solver_start(&sv, d_b, d_x, tol, strict);  // clears the converged flag, zeroes x
+    if (rc) return rc;
+    rc = enqueue_iterations(&sv, max_iter - 1, 0, false);    // cg.c:459: iter = 1 .. max_iter-1; frozen once converged
+    if (rc) return rc;
+    CGH_HIP(hipMemcpyAsync(d_status, sv.done, sizeof(int) * 4, hipMemcpyDeviceToDevice, g_cgh.stream));
+    return CGH_OK;
+}
+

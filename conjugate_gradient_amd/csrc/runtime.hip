@@ -5,6 +5,8 @@
 
 cgh_context g_cgh;
 
+int cgh_noalloc_setup(int device);  // cg.hip
+
 void cgh_set_error(const char *fmt, ...)
 {
     va_list ap;
@@ -78,6 +80,10 @@ int cgh_init(int device)
     }
     g_cgh.num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     read_env_knobs();  // the environment is read here, once, never in a launch path
+    {
+        const int rc = cgh_noalloc_setup(device);  // address of the built-in workspace on THIS device (cg.hip)
+        if (rc) return rc;
+    }
     CGH_HIP(hipStreamCreateWithFlags(&g_cgh.stream, hipStreamNonBlocking));
     CGH_HIP(hipStreamCreateWithFlags(&g_cgh.comm_stream, hipStreamNonBlocking));
     g_cgh.device = device;

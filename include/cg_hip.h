@@ -164,6 +164,21 @@ typedef struct cgh_cg_report {
 int cgh_cg_solve(const cgh_matrix *m, const double *d_b, double *d_x,
                  const cgh_cg_opts *opts, cgh_cg_report *report, double *h_history);
 
+/* The one entry point that ALLOCATES NOTHING.  It has no counterpart in the reference; it is for callers that cannot call
+ * hipMalloc: code under HIP graph capture, tight serving loops that solve one small system after another, harnesses that
+ * forbid allocation.  It is cgh_cg_solve (same kernels, same launch shapes, same bits) with the solver's workspace
+ * (r, p, A p, the per-workgroup partials, the converged flag) in a __device__ array built into the library: 25.2 MB
+ * that every GPU the library runs on holds until the process ends.  Limits: at most 2^20 = 1048576 rows; strict = 1
+ * only below 4096 rows (CGH_XSUM_MIN_ROWS; longer strict sums need their own allocated workspace) -- anything else is
+ * refused with CGH_EINVAL and a message.  Asynchronous: all max_iter-1 iterations are queued on the library's stream
+ * (the device freezes x, r, p at the converging iteration) and the call returns; after cgh_sync() d_x holds the
+ * solution, d_history[4*k..] = { l1norm(r)/2, r.r, alpha, beta } for k = 0 .. converging iteration (4*max_iter doubles,
+ * later entries untouched), d_status[0] = converging iteration (0 = not converged; return value of the reference =
+ * d_status[0] + 1 or -1), d_status[1..3] reserved.  All calls on one GPU share the one workspace: calls that overlap on
+ * a GPU (two host threads) race. */
+int cgh_cg_solve_noalloc(const cgh_matrix *m, const double *d_b, double *d_x, int max_iter, double tol, int strict,
+                         double *d_history, int *d_status);
+
 /* Resumable form of the same loop (what cgh_cg_solve is built from): the workspace lives in the
  * solver, iterations are queued asynchronously in batches, the host polls when it chooses. */
 typedef struct cgh_solver cgh_solver;
