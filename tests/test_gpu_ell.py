@@ -89,6 +89,10 @@ def test_cg_throughput_mode_trajectory(cga, tag, check_every):
     # by strict mode (bit-exact, test above).  Here: each early iteration is within 1e-10 relative, and the
     # converged solution agrees with the reference's to the solver tolerance.
     assert rel[:11].max() < 1e-10
+    if tag.startswith("poisson"):
+        # the well-conditioned stencil systems keep the bar over the WHOLE solve (measured 3e-11 / 1e-12 / 4e-13); the
+        # OpenFOAM systems drift to 6-10 % late in the solve, as the reference's own COO and upper-ELL solvers do
+        assert rel.max() < 1e-10, rel.max()
     if want_ret > 0:
         xr = g["cg_x"]
         assert np.abs(x.to_host() - xr).max() <= 1e-5 * max(1.0, np.abs(xr).max())
@@ -199,3 +203,33 @@ def test_foam128k_standin_strict_parity(cga):
     assert abs(rep2.ret - ret) <= 1
     m = min(hist2.shape[0], traj.shape[0])
     assert (np.abs(hist2[:m, 0] - traj[:m, 0]) / traj[:m, 0]).max() < 1e-10
+
+
+def test_full_size_256cubed_throughput_vs_strict_200_iterations(cga):
+    """BASELINE config 3 at full size: the headline (throughput, strict=0) mode against the parity mode (strict=1, whose
+    bits are the reference's: test above + test_gpu_xsum) over a long stretch of the solve -- 250 iterations --
+    within 1e-10 relative on l1norm(r)/2 at EVERY iteration (north star), then both run to convergence at
+    tol = 1e-6 * l1norm(r0)/2 and stop at the same iteration."""
+    N = 256
+    n = N ** 3
+    b = cga.DeviceVector(n); x = cga.DeviceVector(n)
+    A = cga.Matrix.poisson(N, N, N, 7, 0x5EED0001, cga.LAYOUT_ELL, b)
+    iters = 250
+    hs = {}
+    for strict in (1, 0):
+        rep, hist = cga.cg_solve(A, b, x, fixed_iters=iters, strict=strict)
+        hs[strict] = hist
+    rel = np.abs(hs[0][:, 0] - hs[1][:, 0]) / hs[1][:, 0]
+    print("\n[256^3, %d iterations] throughput vs strict: max rel dev of l1norm(r)/2 %.3e (at iteration %d)" % (iters, rel.max(), rel.argmax()))
+    assert rel.shape[0] == iters + 1 and rel.max() < 1e-10
+    tol = 1e-6 * hs[1][0, 0]
+    rets = {}
+    for strict in (1, 0):
+        rep, hist = cga.cg_solve(A, b, x, max_iter=3000, tol=tol, strict=strict, check_every=64)
+        rets[strict] = (rep.ret, hist)
+    print("[256^3 to tol %.3e] iterations: strict %d, throughput %d" % (tol, rets[1][0], rets[0][0]))
+    assert rets[1][0] > 0 and abs(rets[0][0] - rets[1][0]) <= 1
+    m = min(rets[0][1].shape[0], rets[1][1].shape[0])
+    relc = np.abs(rets[0][1][:m, 0] - rets[1][1][:m, 0]) / rets[1][1][:m, 0]
+    print("[256^3 to convergence] max rel dev over the whole solve %.3e" % relc.max())
+    assert relc.max() < 1e-10
