@@ -4,6 +4,7 @@ trajectory within 1e-10 relative and iteration count within +-1 (BASELINE.json n
 import numpy as np
 import pytest
 
+import foamio
 import oracle_lib as O
 from gpu_common import setknob, GOLDENS, bits, golden, inputs, same_bits_nan
 
@@ -203,6 +204,17 @@ def test_foam128k_standin_strict_parity(cga):
     assert abs(rep2.ret - ret) <= 1
     m = min(hist2.shape[0], traj.shape[0])
     assert (np.abs(hist2[:m, 0] - traj[:m, 0]) / traj[:m, 0]).max() < 1e-10
+    # config 2 names ELL *and* CSR: the same system through the CSR layout (device conversion of the upper COO, rows in
+    # the reference's accumulation order, exact rows) against the oracle's CSR solver on the upper CSR -- bit-identical
+    s = foamio.poisson_coo(nx, ny, 1, 0x5EED0001, 7)
+    assert np.array_equal(bits(s["diag"]), bits(diag)) and np.array_equal(bits(s["source"]), bits(bh))
+    rp = O.coo_to_csr(n, s["rows"])
+    ret_c, xo_c, traj_c = O.cg(O.FMT_CSR, n, s["diag"], s["U"], s["upper"], rp, s["cols"], 0, s["source"], 1000, 1e-6)
+    assert ret_c == ret and same_bits_nan(traj_c, traj)          # the reference's CSR and full-ELL solvers agree bit for bit
+    Ac = cga.Matrix.from_coo(n, s["diag"], s["upper"], s["rows"], s["cols"], cga.LAYOUT_CSR)
+    Ac.set_exact_rows(True)
+    rep3, hist3 = cga.cg_solve(Ac, b, x, max_iter=1000, tol=1e-6, strict=1)
+    assert rep3.ret == ret_c and same_bits_nan(hist3, traj_c) and np.array_equal(bits(x.to_host()), bits(xo_c))
 
 
 def test_full_size_256cubed_throughput_vs_strict_200_iterations(cga):

@@ -1,5 +1,7 @@
-"""CPU-only: the C parser of libcg_hip (include/parser.h, reference src/parser.c:29-177) against the numpy reader of the
-same fixtures."""
+"""CPU-only: the C parser of libcg_hip (include/parser.h, reference src/parser.c:29-177) against what the REFERENCE's own
+parser returned for the same files (tests/golden/golden_parser.npz, written by oracle/gen_golden_parser.py from
+oracle/_ref/libref.so = the reference compiled from its sources), bit for bit; the numpy reader of tests/foamio.py, which
+feeds the other tests, is checked against the same goldens."""
 import ctypes as C
 import os
 
@@ -36,6 +38,12 @@ def test_parse_system_file(name):
     cnt = C.c_int(-1)
     assert L.parseDoubleArray(fp, b"no_such_keyword", C.byref(cnt)) is None
     libc.fclose(fp)
+    ref = np.load(os.path.join(foamio.GOLDEN, "golden_parser.npz"))
+    for key in ("source", "diag", "upper", "upperAddr", "lowerAddr"):
+        r = ref["%s_%s" % (name, key)]
+        assert got[key].dtype == r.dtype and got[key].shape == r.shape, key
+        assert np.array_equal(got[key].view(np.uint64) if r.dtype == np.float64 else got[key],
+                              r.view(np.uint64) if r.dtype == np.float64 else r), key
     assert np.array_equal(got["source"], want["source"]) and np.array_equal(got["diag"], want["diag"])
     assert np.array_equal(got["upper"], want["upper"])
     assert np.array_equal(got["upperAddr"], want["cols"]) and np.array_equal(got["lowerAddr"], want["rows"])
@@ -47,4 +55,5 @@ def test_parse_system_file(name):
         phi = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_double)), shape=(2000,)).copy()
         libc.free(ptr)
         libc.fclose(fp)
+        assert np.array_equal(phi.view(np.uint64), ref["phi_2000"].view(np.uint64))
         assert np.array_equal(phi, foamio.read_foam_field(os.path.join(foamio.GOLDEN, "Phi_2000")))
