@@ -91,6 +91,8 @@ def lib():
     L.cgh_solver_iterate.argtypes = [vp, C.c_int, C.c_int]
     L.cgh_solver_poll.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.cgh_solver_history.argtypes = [vp, C.c_int, C.c_int, dp]
+    L.cgh_solver_rebase.argtypes = [vp]
+    L.cgh_solver_base.argtypes = [vp]
     L.cgh_solver_spmv_ms.argtypes = [vp, dp]
     L.cgh_solver_residual.argtypes = [vp]
     L.cgh_solver_residual.restype = vp

@@ -20,6 +20,7 @@
 // makes the whole trajectory bit-identical to the reference's; it is the parity mode, not the
 // throughput mode.
 #include <cmath>
+#include <stdexcept>
 #include <vector>
 
 #include "cgh_internal.h"
@@ -84,7 +85,8 @@ struct cgh_solver {
     const cgh_matrix *m = nullptr;
     int64_t           n = 0;
     int               capacity = 0;   // iterations the history can hold
-    int               queued = 0;     // iterations queued since start
+    int               queued = 0;     // iterations queued since start (or since the last rebase)
+    int               base = 0;       // iterations finished before the current history window (cgh_solver_rebase)
     int               vgrid = 0;
     bool              strict = false;
     int               precond = CGH_PRECOND_NONE;
@@ -223,6 +225,7 @@ int cgh_solver_start(cgh_solver *sv, const double *d_b, double *d_x, double tol,
     sv->tol = tol;
     sv->strict = strict != 0;
     sv->queued = 0;
+    sv->base = 0;
     for (hipEvent_t e : sv->kev) (void)hipEventDestroy(e);
     sv->kev.clear();
     for (auto &g : sv->graphs) (void)hipGraphExecDestroy(g.second);  // the captured launches carry x, b, tol, strict
@@ -426,25 +429,67 @@ int cgh_solver_spmv_ms(cgh_solver *sv, double *ms_avg)
 
 const double *cgh_solver_residual(const cgh_solver *sv) { return sv ? sv->r : nullptr; }
 
-int cgh_cg_solve(const cgh_matrix *m, const double *d_b, double *d_x, const cgh_cg_opts *opts, cgh_cg_report *rep,
-                 double *h_history)
+// The device history holds `capacity`+1 entries; a solve longer than that continues in a fresh window: the last entry
+// becomes entry 0 (the kernels of iteration k read entry k-1), the device-side iteration counters restart, and the
+// iterations finished so far are counted in sv->base.  Only between polls, and only while not converged.
+int cgh_solver_rebase(cgh_solver *sv)
+{
+    CGH_REQUIRE_READY(CGH_ENODEV);
+    if (!sv) return CGH_EINVAL;
+    if (sv->queued == 0) return CGH_OK;
+    hipStream_t s = g_cgh.stream;
+    CGH_HIP(hipMemcpyAsync(sv->hist, sv->hist + (size_t)sv->queued * HIST, sizeof(double) * HIST, hipMemcpyDeviceToDevice, s));
+    CGH_HIP(hipMemsetAsync(sv->done + 1, 0, sizeof(int) * 2, s));
+    sv->base += sv->queued;
+    sv->queued = 0;
+    return CGH_OK;
+}
+
+int cgh_solver_base(const cgh_solver *sv) { return sv ? sv->base : 0; }
+
+} // extern "C"
+
+namespace {
+struct event_pair {
+    hipEvent_t a = nullptr, b = nullptr;
+    ~event_pair()
+    {
+        if (a) (void)hipEventDestroy(a);
+        if (b) (void)hipEventDestroy(b);
+    }
+};
+constexpr int HISTORY_WINDOW = 4096;  // iterations of history the device keeps at a time (128 KB)
+
+void copy_history(void *ctx, int first, int count, const double *e, int, const cgh_cg_report *)
+{
+    memcpy((double *)ctx + (size_t)HIST * first, e, sizeof(double) * HIST * (size_t)count);
+}
+} // namespace
+
+// cgh_cg_solve with the history delivered in pieces: sink(ctx, first, count, entries, converged_iteration, report) is
+// called with entries [first, first+count) (4 doubles each; first = 0 comes with report->r0 / initial_res filled in) as
+// the host fetches them -- the memory of a solve does not grow with max_iter (the reference's loop is O(1) in it).
+int cgh_cg_solve_sink(const cgh_matrix *m, const double *d_b, double *d_x, const cgh_cg_opts *opts, cgh_cg_report *rep,
+                      cgh_history_sink sink, void *ctx)
 {
     CGH_REQUIRE_READY(CGH_ENODEV);
     if (!m || !d_b || !d_x || !opts || !rep) {
         cgh_set_error("cgh_cg_solve: NULL argument");
         return CGH_EINVAL;
     }
-    const bool   fixed = opts->fixed_iters > 0;
-    const int    max_iter = fixed ? opts->fixed_iters + 1 : opts->max_iter;
-    const double tol = fixed ? -1.0 : opts->tol;  // l1/2 >= 0 is never < -1: no convergence in benchmark mode
-    const int    check = opts->check_every > 0 ? opts->check_every : 32;
+    const bool    fixed = opts->fixed_iters > 0;
+    const int64_t max_iter = fixed ? (int64_t)opts->fixed_iters + 1 : (int64_t)opts->max_iter;
+    const double  tol = fixed ? -1.0 : opts->tol;  // l1/2 >= 0 is never < -1: no convergence in benchmark mode
+    const int     check = opts->check_every > 0 ? opts->check_every : 32;
     memset(rep, 0, sizeof *rep);
     rep->ret = -1;
     if (m->n <= 0 || max_iter < 1) {
-        cgh_set_error("cgh_cg_solve: n=%lld max_iter=%d", (long long)m->n, max_iter);
+        cgh_set_error("cgh_cg_solve: n=%lld max_iter=%lld", (long long)m->n, (long long)max_iter);
         return CGH_EINVAL;
     }
-    cgh_solver *sv = cgh_solver_create(m, max_iter);
+    const int64_t total = max_iter - 1;  // reference loop: iter = 1 .. max_iter-1 (cg.c:459)
+    const int     window = (int)(total < HISTORY_WINDOW ? (total < 1 ? 1 : total) : HISTORY_WINDOW);
+    cgh_solver   *sv = cgh_solver_create(m, window);
     if (!sv) return CGH_ENOMEM;
     struct guard {
         cgh_solver *p;
@@ -457,42 +502,72 @@ int cgh_cg_solve(const cgh_matrix *m, const double *d_b, double *d_x, const cgh_
     if (rc) return rc;
     CGH_HIP(hipMemcpyAsync(rep->r0, sv->r, sizeof(double) * (m->n < 5 ? m->n : 5), hipMemcpyDeviceToHost, s));
 
-    hipEvent_t ev0, ev1;
-    CGH_HIP(hipEventCreate(&ev0));
-    CGH_HIP(hipEventCreate(&ev1));
-    CGH_HIP(hipEventRecord(ev0, s));
-    int done_iter = 0;
-    const int total = max_iter - 1;  // reference loop: iter = 1 .. max_iter-1 (cg.c:459)
-    while (sv->queued < total && done_iter == 0) {
-        int chunk = total - sv->queued;
+    event_pair ev;
+    CGH_HIP(hipEventCreate(&ev.a));
+    CGH_HIP(hipEventCreate(&ev.b));
+    CGH_HIP(hipEventRecord(ev.a, s));
+    std::vector<double> hh((size_t)HIST * (window + 1));
+    int     done_iter = 0;       // converging iteration inside the current window (0 = none yet)
+    int     delivered = -1;      // last entry of the current window already handed to the sink
+    double  last_res = 0.0;
+    // hand entries (delivered, upto] of the current window to the sink
+    auto deliver = [&](int upto, int done_local) -> int {
+        if (upto <= delivered) return CGH_OK;
+        const int first = delivered + 1, count = upto - delivered;
+        int       rc2 = cgh_solver_history(sv, first, count, hh.data());
+        if (rc2) return rc2;
+        if (sv->base == 0 && first == 0) rep->initial_res = hh[0];
+        last_res = hh[(size_t)HIST * (count - 1)];
+        if (sink) sink(ctx, sv->base + first, count, hh.data(), done_local ? sv->base + done_local : 0, rep);
+        delivered = upto;
+        return CGH_OK;
+    };
+    while ((int64_t)sv->base + sv->queued < total && done_iter == 0) {
+        if (sv->queued == window) {  // the window is full and nothing converged in it: hand it over, start the next one
+            rc = deliver(sv->queued, 0);
+            if (rc) return rc;
+            rc = cgh_solver_rebase(sv);
+            if (rc) return rc;
+            delivered = 0;  // entry 0 of the new window is the old window's last entry: already delivered
+        }
+        int64_t chunk = total - sv->base - sv->queued;
+        if (chunk > window - sv->queued) chunk = window - sv->queued;
         if (!fixed && chunk > check) chunk = check;
-        rc = cgh_solver_iterate(sv, chunk, opts->time_kernels);
+        rc = cgh_solver_iterate(sv, (int)chunk, opts->time_kernels);
         if (rc) return rc;
         if (!fixed) {
             rc = cgh_solver_poll(sv, &done_iter, nullptr);
             if (rc) return rc;
         }
     }
-    CGH_HIP(hipEventRecord(ev1, s));
+    CGH_HIP(hipEventRecord(ev.b, s));
     rc = cgh_solver_poll(sv, &done_iter, nullptr);
     if (rc) return rc;
     float ms = 0.f;
-    CGH_HIP(hipEventElapsedTime(&ms, ev0, ev1));
-    (void)hipEventDestroy(ev0);
-    (void)hipEventDestroy(ev1);
+    CGH_HIP(hipEventElapsedTime(&ms, ev.a, ev.b));
     rep->solve_ms = ms;
     if (opts->time_kernels) cgh_solver_spmv_ms(sv, &rep->spmv_ms_avg);
 
-    const int executed = done_iter ? done_iter : sv->queued;
-    rep->iterations = executed;
-    rep->ret = done_iter ? done_iter + 1 : -1;
-    std::vector<double> hh((size_t)HIST * (executed + 1));
-    rc = cgh_solver_history(sv, 0, executed + 1, hh.data());
+    const int executed_local = done_iter ? done_iter : sv->queued;
+    rep->iterations = sv->base + executed_local;
+    rep->ret = done_iter ? sv->base + done_iter + 1 : -1;
+    rc = deliver(executed_local, done_iter);
     if (rc) return rc;
-    rep->initial_res = hh[0];
-    rep->final_res = hh[(size_t)HIST * executed];
-    if (h_history) memcpy(h_history, hh.data(), hh.size() * sizeof(double));
+    rep->final_res = last_res;
     return CGH_OK;
+}
+
+extern "C" {
+
+int cgh_cg_solve(const cgh_matrix *m, const double *d_b, double *d_x, const cgh_cg_opts *opts, cgh_cg_report *rep,
+                 double *h_history)
+{
+    try {
+        return cgh_cg_solve_sink(m, d_b, d_x, opts, rep, h_history ? copy_history : (cgh_history_sink) nullptr, h_history);
+    } catch (const std::exception &e) {
+        cgh_set_error("cgh_cg_solve: %s", e.what());
+        return CGH_ENOMEM;
+    }
 }
 
 } // extern "C"

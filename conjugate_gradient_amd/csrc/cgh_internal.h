@@ -156,6 +156,12 @@ void cgh_ell_dict_free(const cgh_matrix *m);
 cgh_matrix *cgh_matrix_from_entries_device(int64_t n, int64_t U, const double *d_diag, const double *d_upper,
                                            const int *d_rows, const int *d_cols, int layout);
 
+// cg.hip: cgh_cg_solve with the history handed over window by window (dropin.hip prints from it)
+typedef void (*cgh_history_sink)(void *ctx, int first, int count, const double *entries, int converged_iteration,
+                                 const cgh_cg_report *report);
+int cgh_cg_solve_sink(const cgh_matrix *m, const double *d_b, double *d_x, const cgh_cg_opts *opts, cgh_cg_report *rep,
+                      cgh_history_sink sink, void *ctx);
+
 // xsum.hip -- order-exact parallel sums (the strict mode of large vectors)
 struct cgh_xsum;
 cgh_xsum *cgh_xsum_create(int64_t n);

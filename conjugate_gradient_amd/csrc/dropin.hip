@@ -11,6 +11,7 @@
 // bit-identical trajectory, the default at every size -- one lane below 4096 rows, the order-exact parallel
 // sums of xsum.hip above; fast = tree reductions, ~2.4x faster per iteration at 16.7M rows).
 #include <cmath>
+#include <new>
 #include <vector>
 
 #include "cgh_internal.h"
@@ -119,6 +120,40 @@ __global__ __launch_bounds__(256) void narrow_cols(int64_t total, const uint64_t
     for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < total; k += (int64_t)gridDim.x * 256) out[k] = (int)in[k];
 }
 
+// generic row-major ELL (pad = any negative column) -> slot-major with pad = -1; a row's slot order is kept
+__global__ __launch_bounds__(256) void ell_rowmajor_to_slotmajor(int64_t n, int K, const double *__restrict__ ev, const int *__restrict__ ec,
+                                                                double *__restrict__ sv, int *__restrict__ sc)
+{
+    const int64_t total = n * (int64_t)K;
+    for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < total; k += (int64_t)gridDim.x * 256) {
+        const int64_t i = k % n;           // k walks the slot-major output: coalesced stores, strided loads
+        const int     s = (int)(k / n);
+        const int     c = ec[i * K + s];
+        sv[k] = ev[i * K + s];
+        sc[k] = c >= 0 ? c : -1;
+    }
+}
+
+// an ELL matrix whose arrays are allocated but not filled (the callers fill them on the device)
+cgh_matrix *ell_shell(int n, int K, int64_t nnz_off)
+{
+    cgh_matrix *m = new (std::nothrow) cgh_matrix();
+    if (!m) return nullptr;
+    m->n = n;
+    m->K = K;
+    m->layout = CGH_LAYOUT_ELL;
+    m->stored = (int64_t)n * K;
+    m->nnz_off = nnz_off;
+    m->diag = (double *)cgh_alloc(sizeof(double) * (size_t)(n > 0 ? n : 1));
+    m->vals = (double *)cgh_alloc(sizeof(double) * (size_t)(m->stored > 0 ? m->stored : 1));
+    m->cols = (int *)cgh_alloc(sizeof(int) * (size_t)(m->stored > 0 ? m->stored : 1));
+    if (!m->diag || !m->vals || !m->cols) {
+        cgh_matrix_free(m);
+        return nullptr;
+    }
+    return m;
+}
+
 __global__ __launch_bounds__(256) void sub_kernel(int64_t n, const double *a, const double *b, double *out, int add)
 {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
@@ -156,40 +191,64 @@ void print_prologue(const char *banner, const cgh_cg_report &rep, int64_t n)
     printf("Initial residual norm: %f\n", rep.initial_res);
 }
 
+// The solver's chatter comes out of the history as the solve hands it over, window by window: nothing here grows with
+// max_iter (the reference's loop keeps no history at all).
+struct chatter {
+    const char *banner;
+    int64_t     n;
+    bool        prologue_done = false;
+};
+
+void print_window(void *ctx, int first, int count, const double *e, int converged, const cgh_cg_report *rep)
+{
+    chatter *c = (chatter *)ctx;
+    if (quiet()) return;
+    if (!c->prologue_done) {
+        print_prologue(c->banner, *rep, c->n);
+        c->prologue_done = true;
+    }
+    for (int k = 0; k < count; ++k) {
+        const int it = first + k;
+        if (it == 0) continue;                         // entry 0 is the initial residual (printed by the prologue)
+        if (converged > 0 && it == converged) break;   // the converging iteration prints the final line instead
+        printf("Iteration %d: Residual norm = %g\n", it, e[(size_t)4 * k]);
+    }
+}
+
 int run_cg(const char *banner, const cgh_matrix *m, const double *b, double *x, int max_iter, double tol)
 {
-    const int64_t  n = m->n;
-    dbuf<double>   db(b, (size_t)n), dx((size_t)n);
-    if (!db.ok() || !dx.ok()) return -1;
-    cgh_cg_opts opts;
-    memset(&opts, 0, sizeof opts);
-    opts.max_iter = max_iter;
-    opts.tol = tol;
-    opts.strict = strict_for(n);
-    opts.check_every = 32;
-    cgh_cg_report       rep;
-    std::vector<double> hist((size_t)4 * (max_iter > 0 ? max_iter + 1 : 1));
-    if (max_iter < 1) {
-        // the reference still zeroes x, computes r0 and prints; with no iterations it reports non-convergence
-        opts.max_iter = 1;
-    }
-    if (cgh_cg_solve(m, db.p, dx.p, &opts, &rep, hist.data()) != CGH_OK) return -1;
-    if (dx.get(x) != CGH_OK) return -1;
-    print_prologue(banner, rep, n);
-    if (!quiet()) {
-        const int last = rep.iterations;
-        for (int it = 1; it <= last; ++it) {
-            if (rep.ret > 0 && it == last) break;  // the converging iteration prints the final line instead
-            printf("Iteration %d: Residual norm = %g\n", it, hist[(size_t)4 * it]);
+    try {
+        const int64_t n = m->n;
+        dbuf<double>  db(b, (size_t)n), dx((size_t)n);
+        if (!db.ok() || !dx.ok()) return -1;
+        cgh_cg_opts opts;
+        memset(&opts, 0, sizeof opts);
+        // the reference still zeroes x, computes r0 and prints when max_iter < 1; with no iterations it reports non-convergence
+        opts.max_iter = max_iter < 1 ? 1 : max_iter;
+        opts.tol = tol;
+        opts.strict = strict_for(n);
+        opts.check_every = 32;
+        cgh_cg_report rep;
+        chatter       c{banner, n};
+        if (cgh_cg_solve_sink(m, db.p, dx.p, &opts, &rep, print_window, &c) != CGH_OK) return -1;
+        if (dx.get(x) != CGH_OK) return -1;
+        if (!quiet()) {
+            if (!c.prologue_done) print_prologue(banner, rep, n);
+            if (rep.ret > 0) {
+                printf("\nResidual norm: %.g\n", rep.final_res);
+            } else {
+                printf("Maximum iterations reached without convergence.\n");
+                printf("Residual norm: %g\n", rep.final_res);
+            }
         }
-        if (rep.ret > 0) {
-            printf("\nResidual norm: %.g\n", rep.final_res);
-        } else {
-            printf("Maximum iterations reached without convergence.\n");
-            printf("Residual norm: %g\n", rep.final_res);
-        }
+        return rep.ret;
+    } catch (const std::exception &e) {  // nothing may unwind through the extern "C" callers
+        cgh_set_error("conjugate_gradient_*: %s", e.what());
+        return -1;
+    } catch (...) {
+        cgh_set_error("conjugate_gradient_*: unknown failure");
+        return -1;
     }
-    return rep.ret;
 }
 
 // stop: memory position (in the caller's ELL arrays) of the first malformed entry, -1 if none: everything from there on is
@@ -323,24 +382,28 @@ void mv_ell_symmetric_full_colmajor(int n, int max_nnz_row, double *diag, double
     if (g.m) spmv_host(g.m, x, y);
 }
 
-// reference src/ell.c:1045-1081 (uint64_t columns; the reference narrows them to int before use)
+// reference src/ell.c:1045-1081 (uint64_t columns; the reference narrows them to int before use): the wide ids are
+// uploaded once and narrowed on the device straight into the matrix
 void mv_ell_symmetric_full_colmajor_sdtint(int n, int max_nnz_row, double *diag, double *ell_values, uint64_t *ell_cols,
                                            double *x, double *y)
 {
-    if (!ensure_ready()) return;
-    const int64_t  total = (int64_t)n * max_nnz_row;
+    if (!ensure_ready() || n <= 0) return;
+    const int64_t total = (int64_t)n * max_nnz_row;
+    int64_t       live = 0;
+    for (int64_t k = 0; k < total; ++k) live += (int)ell_cols[k] != -1;
     dbuf<uint64_t> wide(ell_cols, (size_t)total);
-    dbuf<int>      narrow((size_t)total);
-    if (!wide.ok() || !narrow.ok()) return;
-    if (total > 0) hipLaunchKernelGGL(narrow_cols, dim3(grid_for(total)), dim3(256), 0, g_cgh.stream, total, (const uint64_t *)wide.p, narrow.p);
-    std::vector<int> h((size_t)total);
-    if (narrow.get(h.data()) != CGH_OK) return;
-    mat_guard g{cgh_matrix_from_ell_host(n, max_nnz_row, diag, ell_values, h.data())};
-    if (g.m) spmv_host(g.m, x, y);
+    mat_guard      g{ell_shell(n, max_nnz_row, live)};
+    if (!wide.ok() || !g.m) return;
+    if (cgh_h2d(g.m->diag, diag, sizeof(double) * (size_t)n) != CGH_OK || cgh_h2d(g.m->vals, ell_values, sizeof(double) * (size_t)total) != CGH_OK)
+        return;
+    if (total > 0)
+        hipLaunchKernelGGL(narrow_cols, dim3(grid_for(total)), dim3(256), 0, g_cgh.stream, total, (const uint64_t *)wide.p, g.m->cols);
+    if (hipGetLastError() != hipSuccess) return;
+    spmv_host(g.m, x, y);
 }
 
-// reference src/ell.c:946-999.  A stored column <= its row makes the reference print and return with y
-// partially accumulated; that partial state is not reproduced: the error is printed and y is left untouched.
+// reference src/ell.c:946-999.  A stored column <= its row makes the reference print and return with y partially
+// accumulated: the message and that partial y are reproduced (the expansion stops at the offending entry).
 void mv_ell_symmetric_upper_colmajor(int n, int max_nnz_row, double *diag, double *ell_values, int *ell_cols, double *x, double *y)
 {
     if (!ensure_ready()) return;
@@ -386,22 +449,24 @@ void mv_ell_symmetric_upper_opt(int n, int max_nnz_row, double *diag, double *el
     mv_ell_symmetric_upper(n, max_nnz_row, diag, ell_values, ell_cols, x, y);
 }
 
-// reference src/ell.c:136-159: generic row-major ELL (no separate diagonal, pad = negative column)
+// reference src/ell.c:136-159: generic row-major ELL (no separate diagonal, pad = negative column): uploaded as it is,
+// turned slot-major on the device (zero diagonal: 0.0 + 0.0*x starts each row's sum); per-row order (slots 0..K-1) is kept
 void mv_ell(int n, int max_nnz_row, double *ell_values, int *ell_cols, double *x, double *y)
 {
-    if (!ensure_ready()) return;
-    // transpose to slot-major on the host side of the boundary, zero diagonal; per-row order (slots 0..K-1) is kept
-    const int64_t       total = (int64_t)n * max_nnz_row;
-    std::vector<double> ev((size_t)total), zero((size_t)n, 0.0);
-    std::vector<int>    ec((size_t)total);
-    for (int i = 0; i < n; ++i)
-        for (int s = 0; s < max_nnz_row; ++s) {
-            const int c = ell_cols[(size_t)i * max_nnz_row + s];
-            ev[(size_t)s * n + i] = ell_values[(size_t)i * max_nnz_row + s];
-            ec[(size_t)s * n + i] = c >= 0 ? c : -1;
-        }
-    mat_guard g{cgh_matrix_from_ell_host(n, max_nnz_row, zero.data(), ev.data(), ec.data())};
-    if (g.m) spmv_host(g.m, x, y);
+    if (!ensure_ready() || n <= 0) return;
+    const int64_t total = (int64_t)n * max_nnz_row;
+    int64_t       live = 0;
+    for (int64_t k = 0; k < total; ++k) live += ell_cols[k] >= 0;
+    dbuf<double> rv(ell_values, (size_t)total);
+    dbuf<int>    rc(ell_cols, (size_t)total);
+    mat_guard    g{ell_shell(n, max_nnz_row, live)};
+    if (!rv.ok() || !rc.ok() || !g.m) return;
+    if (hipMemsetAsync(g.m->diag, 0, sizeof(double) * (size_t)n, g_cgh.stream) != hipSuccess) return;
+    if (total > 0)
+        hipLaunchKernelGGL(ell_rowmajor_to_slotmajor, dim3(grid_for(total)), dim3(256), 0, g_cgh.stream, (int64_t)n, max_nnz_row,
+                           (const double *)rv.p, (const int *)rc.p, g.m->vals, g.m->cols);
+    if (hipGetLastError() != hipSuccess) return;
+    spmv_host(g.m, x, y);
 }
 
 static int max_nnz_row(int n, int upper_nnz, const int *rows, const int *cols, bool both, bool to_stderr)

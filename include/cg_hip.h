@@ -160,7 +160,8 @@ typedef struct cgh_cg_report {
 } cgh_cg_report;
 
 /* h_history (may be NULL) receives 4 doubles per iteration k=0..iterations:
- * { l1norm(r)/2, r.r, alpha, beta } (NaN where the reference computes none). Needs 4*max_iter doubles. */
+ * { l1norm(r)/2, r.r, alpha, beta } (NaN where the reference computes none). Needs 4*max_iter doubles
+ * of HOST memory if given; the device keeps a bounded window of it whatever max_iter is. */
 int cgh_cg_solve(const cgh_matrix *m, const double *d_b, double *d_x,
                  const cgh_cg_opts *opts, cgh_cg_report *report, double *h_history);
 
@@ -189,6 +190,12 @@ int           cgh_solver_start(cgh_solver *s, const double *d_b, double *d_x, do
 int           cgh_solver_iterate(cgh_solver *s, int count, int time_kernels);
 int           cgh_solver_poll(cgh_solver *s, int *done_iter, int *queued);
 int           cgh_solver_history(cgh_solver *s, int first, int count, double *h_out);
+/* A solve longer than iteration_capacity continues in a fresh history window: call between polls, while not converged.
+ * The last entry becomes entry 0, iteration numbers (cgh_solver_poll, cgh_solver_history) restart at 0 and
+ * cgh_solver_base() returns how many iterations lie before the window.  cgh_cg_solve uses windows of 4096 iterations,
+ * so its device memory does not grow with max_iter (the reference's loop is O(1) in max_iter, src/cg.c:414-508). */
+int           cgh_solver_rebase(cgh_solver *s);
+int           cgh_solver_base(const cgh_solver *s);
 int           cgh_solver_spmv_ms(cgh_solver *s, double *ms_avg);
 const double *cgh_solver_residual(const cgh_solver *s);   /* device pointer to r */
 

@@ -339,3 +339,21 @@ def test_tiny_and_odd_sizes(api, n):
         ret, x, oret, ox = _coo_solve(api, n, diag, upper, rows, cols, b, mi, tol)
         assert ret == oret, (n, mi, tol, ret, oret)
         assert np.array_equal(bits(x), bits(ox)), (n, mi, tol)
+
+
+def test_huge_max_iter_is_served_in_bounded_memory():
+    """max_iter = INT_MAX ("until converged"): the reference's loop is O(1) in max_iter (src/cg.c:414-508) and so is the
+    drop-in -- the history lives in a bounded window -- so the call returns the reference's 254 on foam-2000."""
+    import ctypes as C
+    import conjugate_gradient_amd as cga
+    L = cga.lib()
+    s, g = inputs("cylinder_2000"), golden("cylinder_2000")
+    n, K = s["n"], int(g["K_full"])
+    dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int)
+    L.conjugate_gradient_ell_full_colmajor.argtypes = [C.c_int, dp, C.c_int, dp, ip, C.c_int, dp, dp, C.c_int, C.c_double]
+    ev = np.ascontiguousarray(g["ell_full_vals"]); ec = np.ascontiguousarray(g["ell_full_cols"])
+    diag = np.ascontiguousarray(s["diag"]); b = np.ascontiguousarray(s["source"]); x = np.full(n, 5.0)
+    ret = L.conjugate_gradient_ell_full_colmajor(n, diag.ctypes.data_as(dp), s["U"], ev.ctypes.data_as(dp), ec.ctypes.data_as(ip), K,
+                                                 b.ctypes.data_as(dp), x.ctypes.data_as(dp), 2 ** 31 - 1, float(g["tol"]))
+    assert ret == int(g["cg_ret"][4]) == 254
+    assert np.array_equal(x.view(np.uint64), np.ascontiguousarray(g["cg_x"]).view(np.uint64))

@@ -245,3 +245,28 @@ def test_full_size_256cubed_throughput_vs_strict_200_iterations(cga):
     relc = np.abs(rets[0][1][:m, 0] - rets[1][1][:m, 0]) / rets[1][1][:m, 0]
     print("[256^3 to convergence] max rel dev over the whole solve %.3e" % relc.max())
     assert relc.max() < 1e-10
+
+
+def test_long_solve_crosses_history_windows(cga):
+    """The device keeps 4096 iterations of history at a time (the reference's loop keeps none): a strict solve of the
+    32k OpenFOAM system over 9000 iterations crosses two window boundaries (cgh_solver_rebase) and still reproduces the
+    oracle's trajectory bit for bit, the throughput mode its own trajectory from an unbroken solver."""
+    s, g = inputs("cylinder_32k"), golden("cylinder_32k")
+    n, K = s["n"], int(g["K_full"])
+    A = cga.Matrix.from_ell(n, K, s["diag"], g["ell_full_vals"], g["ell_full_cols"])
+    b = cga.DeviceVector.from_host(s["source"]); x = cga.DeviceVector(n)
+    max_iter = 9000
+    tol = -1.0    # never met: the loop runs on past convergence (1e-6 after 1080 iterations), through an exactly-zero residual into NaNs -- in the reference's arithmetic too
+    ret, xo, traj = O.cg(O.FMT_ELL_FULL, n, s["diag"], s["U"], g["ell_full_vals"], g["ell_full_cols"], None, K, s["source"], max_iter, tol)
+    rep, hist = cga.cg_solve(A, b, x, max_iter=max_iter, tol=tol, strict=1)
+    assert rep.ret == ret == -1 and rep.iterations == traj.shape[0] - 1 == max_iter - 1
+    assert same_bits_nan(hist, traj) and np.array_equal(bits(x.to_host()), bits(xo))
+    # throughput mode: windows (cgh_cg_solve) against one solver whose history holds the whole solve
+    rep0, hist0 = cga.cg_solve(A, b, x, fixed_iters=8500, strict=0)
+    sv = cga.Solver(A, 8500)
+    x2 = cga.DeviceVector(n)
+    sv.start(b, x2, tol=-1.0, strict=0)
+    sv.iterate(8500)
+    sv.poll()
+    assert same_bits_nan(hist0, sv.history(0, 8501)) and np.array_equal(bits(x.to_host()), bits(x2.to_host()))
+    sv.free()
