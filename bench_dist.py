@@ -2,8 +2,8 @@
 row-block (z-slab) partitioned over the ranks, halo exchange + all-reduces over RCCL inside libcg_hip.
 The launcher (python -m torch.distributed.run) only provides RANK / WORLD_SIZE / LOCAL_RANK: the ranks of the one node
 hand the ncclUniqueIds over through a file in /tmp named after the launcher's pid, and every later exchange (barriers,
-max-over-ranks) is an RCCL all-reduce of the library's own communicator.  torch is not imported here: its wheel brings
-its own copies of the HIP runtime and RCCL, and a process that holds both sets aborts at exit.
+max-over-ranks) is an RCCL all-reduce of the library's own communicator.  torch is not imported here: nothing on this path needs it (its wheel brings a second HIP
+runtime and RCCL into the process; harmless since the library loads its RCCL RTLD_LOCAL, DESIGN.md section 1, but dead weight).
 
 The JSON line's `value` is the workload bench.py was asked for (default p7_256: the 16.7M-row matrix of BASELINE's
 north-star target split over the N GPUs, strong scaling).  For the default workload the line also carries

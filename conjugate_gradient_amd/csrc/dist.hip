@@ -64,11 +64,15 @@ struct rccl_api {
 int load_rccl()
 {
     if (g_rccl.handle) return CGH_OK;
-    // The ROCm installation's RCCL (the one this library's HIP runtime belongs to) first; a process that wants it
-    // must call cgh_comm_preload() before anything else loads another librccl.so.1 (e.g. before `import torch`).
+    // The ROCm installation's RCCL (the one this library's HIP runtime belongs to) first.  RTLD_LOCAL on purpose: a
+    // global load promotes librccl.so.1 AND its dependencies (libamdhip64.so.7, libhsa-runtime64.so.1) into the
+    // process-wide lookup scope, where their hip*/nccl* symbols interpose those of a second ROCm set loaded later
+    // (PyTorch bundles one under other file names, so the loader does not merge them); a process then runs half of
+    // one runtime against the other and aborts in the exit handlers (tools/exit_probe.py).
+    // Every entry point is taken with dlsym from the handle, so nothing here needs the global scope.
     const char *names[] = {"/opt/rocm/lib/librccl.so.1", "librccl.so.1", "librccl.so"};
     for (const char *nm : names) {
-        g_rccl.handle = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
+        g_rccl.handle = dlopen(nm, RTLD_NOW | RTLD_LOCAL);
         if (g_rccl.handle) break;
     }
     if (!g_rccl.handle) {
