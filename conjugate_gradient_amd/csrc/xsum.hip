@@ -8,9 +8,9 @@
 //                  workgroup of xs_summarize adds up the sums of the groups before it)
 //   xs_summarize   one workgroup per group: predicted running sum at each cell start -> assumed binade ->
 //                  integer summary {D, lo, hi} of every cell, and their join per group
-//   xs_drive       one wave per sum: walks the group summaries 64 at a time (one per lane, validated and applied
-//                  with a wave prefix sum), drops to the cells of the first group that fails and to the elements
-//                  of the first cell that fails, then finalises like seq_sums (alpha / beta / residual / done flag)
+//   xs_drive       one workgroup per sum: 16 waves stage the summaries in LDS and join them 64 at a time, one wave
+//                  walks the joined summaries (validated and applied with a wave prefix sum), drops into the batch,
+//                  the group and the cell that fails, then finalises like seq_sums (alpha / beta / residual / done)
 // Everything the driver skips was validated by integer arithmetic that is exact, so the result does not depend on
 // the prediction: a wrong prediction only sends a cell down the element-by-element path.
 #include "cgh_internal.h"
@@ -24,6 +24,7 @@ struct cgh_xsum {
     double     *gprefix = nullptr;   // [2][ngroups]
     xs_summary *cells = nullptr;     // [2][ncells]
     xs_summary *groups = nullptr;    // [2][ngroups]
+    double     *xfer = nullptr;      // [4]: the two sums on their way to the finalising workgroup, its ticket
 };
 
 namespace {
@@ -143,14 +144,131 @@ __device__ __forceinline__ xs_summary wave_join(xs_summary q)
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
         xs_summary o;
-        o.D = shfl_down_i64(q.D, off);
-        o.lo = shfl_down_i64(q.lo, off);
-        o.hi = shfl_down_i64(q.hi, off);
+        o.A = shfl_down_i64(q.A, off);
+        o.C = shfl_down_i64(q.C, off);
+        o.Mlo = shfl_down_i64(q.Mlo, off);
+        o.Mhi = shfl_down_i64(q.Mhi, off);
         o.E = __shfl_down(q.E, off, 64);
         o.meta = __shfl_down(q.meta, off, 64);
         // lanes whose partner is beyond the wave keep their own (their value is not used by lane 0's tree)
         if ((int)(threadIdx.x & 63) + off < 64) q = xs_join(q, o);
     }
+    return q;
+}
+
+// ---- cells with one special element (an exact tie, or the element at which the sum enters the next binade): xsum.h.
+// The 16 lanes of a cell (one DPP row; lane `sub` holds elements 8 sub .. 8 sub + 7) build what xs_cell_summary states
+// sequentially.  Called by whole waves; rows that do not need it compute values nobody uses.
+__device__ __forceinline__ int64_t row_excl_scan(int64_t v, int sub)
+{
+    int64_t incl = v;
+#pragma unroll
+    for (int off = 1; off < 16; off <<= 1) {
+        const int64_t o = (int64_t)__shfl_up((long long)incl, off, 16);
+        if (sub >= off) incl += o;
+    }
+    return incl - v;
+}
+__device__ __forceinline__ int64_t row_min(int64_t v)
+{
+#pragma unroll
+    for (int m = 1; m < 16; m <<= 1) {
+        const int64_t o = (int64_t)__shfl_xor((long long)v, m, 16);
+        v = o < v ? o : v;
+    }
+    return v;
+}
+__device__ __forceinline__ int64_t row_max(int64_t v)
+{
+#pragma unroll
+    for (int m = 1; m < 16; m <<= 1) {
+        const int64_t o = (int64_t)__shfl_xor((long long)v, m, 16);
+        v = o > v ? o : v;
+    }
+    return v;
+}
+
+// Out of line, rolled loops over the lane's 8 elements staged in LDS (t): the rare path must not set the register
+// budget of the kernel that holds it.  Returns the summary, or one with meta = -1 if the cell has no single special
+// element.
+__device__ __noinline__ xs_summary xs_special16(const double *t, int32_t E, int32_t neg, int64_t Mt)
+{
+    const int lane = threadIdx.x & 63, sub = lane & 15, row0 = lane & 48;
+    int64_t   T = 0, dk;
+    bool      hard = false;
+#pragma unroll 1
+    for (int k = 0; k < 8; ++k) {
+        const int cls = xs_classify(t[k], E, neg, &dk);
+        hard = hard || cls == 2;
+        T += cls ? 0 : dk;
+    }
+    const int64_t base = row_excl_scan(T, sub);
+    int           kx = 8, ty = 0;
+    int64_t       run = base;
+#pragma unroll 1
+    for (int k = 0; k < 8; ++k) {
+        const int cls = xs_classify(t[k], E, neg, &dk);
+        if (kx == 8 && cls == 1) {
+            kx = k;
+            ty = 1;
+        } else if (kx == 8 && cls == 0 && Mt + run + dk > XS_TWO53 - 2) {
+            kx = k;
+            ty = 2;
+        }
+        run += cls ? 0 : dk;
+    }
+    const unsigned hard_row = (unsigned)(__ballot(hard) >> row0) & 0xffffu;
+    const unsigned spec_row = (unsigned)(__ballot(kx < 8) >> row0) & 0xffffu;
+    bool           valid = !hard_row && spec_row;
+    const int      lstar = spec_row ? (int)__builtin_ctz(spec_row) : 0, src = row0 + lstar;
+    const int      kstar = __shfl(kx, src, 64), type = __shfl(ty, src, 64);
+    // part 1: everything before the special element, in binade E
+    int64_t lo1 = 0, hi1 = 0;
+    run = base;
+#pragma unroll 1
+    for (int k = 0; k < 8; ++k)
+        if (sub < lstar || (sub == lstar && k < kstar)) {
+            xs_classify(t[k], E, neg, &dk);  // (nothing before the first special element is one)
+            run += dk;
+            lo1 = run < lo1 ? run : lo1;
+            hi1 = run > hi1 ? run : hi1;
+        }
+    const int64_t P = shfl_i64(run, src);
+    lo1 = row_min(lo1);
+    hi1 = row_max(hi1);
+    // the special element
+    const double  ts = t[kstar & 7];
+    const double  tau = ldexp(neg ? -ts : ts, 1075 - E), cfl = floor(tau);
+    const int64_t c = shfl_i64((int64_t)cfl, src);
+    const int     whole = __shfl((int)(tau == cfl), src, 64);
+    if (type == 2 && whole) valid = false;  // integer tau at a crossing: a tie in the new binade when W + c is odd
+    // part 2: everything after it, in the binade it leaves the sum in
+    const int32_t E2 = type == 2 ? E + 1 : E;
+    int64_t       T2 = 0;
+    bool          bad2 = false;
+#pragma unroll 1
+    for (int k = 0; k < 8; ++k)
+        if (sub > lstar || (sub == lstar && k > kstar)) {
+            if (xs_classify(t[k], E2, neg, &dk)) bad2 = true, dk = 0;
+            T2 += dk;
+        }
+    const int64_t base2 = row_excl_scan(T2, sub);
+    const int64_t D2 = shfl_i64(base2 + T2, row0 + 15);
+    int64_t       lo2 = 0, hi2 = 0;
+    run = base2;
+#pragma unroll 1
+    for (int k = 0; k < 8; ++k)
+        if (sub > lstar || (sub == lstar && k > kstar)) {
+            if (xs_classify(t[k], E2, neg, &dk)) dk = 0;
+            run += dk;
+            lo2 = run < lo2 ? run : lo2;
+            hi2 = run > hi2 ? run : hi2;
+        }
+    lo2 = row_min(lo2);
+    hi2 = row_max(hi2);
+    if ((unsigned)(__ballot(bad2) >> row0) & 0xffffu) valid = false;  // a second special element
+    xs_summary q = type == 2 ? xs_crossing(P, lo1, hi1, c, D2, lo2, hi2, E, neg, false) : xs_tie(P, lo1, hi1, c, D2, lo2, hi2, E, neg, false);
+    if (!valid) q.meta = -1;
     return q;
 }
 
@@ -184,6 +302,7 @@ __global__ __launch_bounds__(256) void xs_summarize(int64_t n, const double *__r
     __shared__ double     start[2][XS_GROUP];  // predicted running sum at the start of each cell
     __shared__ xs_summary sm[2][XS_GROUP];
     __shared__ double     red[4];
+    __shared__ double     spec[256][9];  // a lane's 8 elements for xs_special16 (rows of 9: no bank conflicts)
     const int     lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // groups == NULL ("flat", few cells): four workgroups per group, one pass of 16 cells each, no group summary --
     // the whole problem is then a handful of workgroups, and their serial depth is what counts
@@ -249,18 +368,23 @@ __global__ __launch_bounds__(256) void xs_summarize(int64_t n, const double *__r
             for (int k = 0; k < 8; ++k) zeros = zeros && t[slot][k] == 0.0;
             const unsigned long long zero_lanes = __ballot(zeros);
             const bool               cell_is_zero = ((zero_lanes >> (lane & 48)) & 0xffffull) == 0xffffull;
+            const bool               cell_bad = ((bad_lanes >> (lane & 48)) & 0xffffull) != 0;
+            xs_summary               q = xs_identity();
+            if (cell < ncells && !cell_is_zero) q = xs_regular(D, lo, hi, usable ? E : 0, neg, cell_bad);
+            // One special element (an exact tie, or the element that takes the predicted mantissa into the next binade):
+            // the plain summary above cannot apply, the summary with that element spelt out can (xsum.h).  Whole waves
+            // enter; ~ln(n) ties and ~log2(n) crossings per sum, so almost none do.
+            const int64_t Mt = xs_mantissa(start[slot][ci]);
+            bool          want = cell < ncells && !cell_is_zero && usable && (cell_bad || Mt > q.Mhi);  // (sub == 0 knows)
+            want = __shfl((int)want, lane & 48, 64) != 0;
+            if (__ballot(want)) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) spec[threadIdx.x][k] = t[slot][k];
+                const xs_summary sp = xs_special16(spec[threadIdx.x], E, neg, Mt);
+                if (want && sp.meta != -1) q = sp;
+            }
             if (sub == 0) {
-                xs_summary q = xs_identity();
-                if (cell < ncells) {
-                    if (!cell_is_zero) {
-                        q.D = D;
-                        q.lo = lo;
-                        q.hi = hi;
-                        q.E = usable ? E : 0;
-                        q.meta = (neg ? 2 : 0) | (((bad_lanes >> (lane & 48)) & 0xffffull) ? XS_IRREGULAR : 0);
-                    }
-                    cells[slot * ncells + cell] = q;
-                }
+                if (cell < ncells) cells[slot * ncells + cell] = q;
                 sm[slot][ci] = q;
             }
         }
@@ -274,14 +398,15 @@ __global__ __launch_bounds__(256) void xs_summarize(int64_t n, const double *__r
 }
 
 // ---------------------------------------------------------------------------------------------- the driver
-// Optional profile of the serial walk (tools/prof_drive.py): lane 0 of the first wave in use adds event counts and
-// 100 MHz ticks into 16 words.  [0] batches of groups, [1] groups walked cell by cell, [2] cells added element by
-// element, [3] ticks in total, [4] ticks inside groups walked cell by cell, [5] ticks inside element chains (incl.
-// waiting for their elements), [6] launches.
-#define XS_PROF_ADD(k, v)                                                   \
-    do {                                                                    \
-        if (prof != nullptr && (threadIdx.x & 63) == 0) prof[k] += (v);     \
-    } while (0)
+// Optional profile of the driver (tools/prof_drive.py): lane 0 of the first sum's waves adds event counts and 100 MHz
+// ticks into 16 words.  [0] batches the walk descended into, [1] groups walked cell by cell, [2] cells added element by
+// element, [3] ticks in total, [4] ticks in phase 1 (staging, batch joins), [5] ticks in phase 2 (the walk), [6] launches,
+// [7] runs with a crossing or a tie applied whole, [8] prefix scans, [9] calls of xs_batch, [10] ticks before phase 1.
+#define XS_PROF_ADD(k, v)                                                                                   \
+    do {                                                                                                    \
+        if (prof != nullptr && (threadIdx.x & 63) == 0)                                                     \
+            __hip_atomic_fetch_add(&prof[k], (long long)(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   \
+    } while (0) /* no-return atomics: nothing waits for them, so counting does not stretch what it counts */
 __device__ __forceinline__ double readlane_f64(double v, int k)
 {
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), k), hi = __builtin_amdgcn_readlane(__double2hiint(v), k);
@@ -304,50 +429,66 @@ __device__ __forceinline__ int64_t readlane_i64(int64_t v, int k)
 }
 
 // Items [start, cnt) of a batch (one summary per lane): apply the longest valid prefix to the running sum s
-// (wave-uniform) and return the index of the first item that does not apply (cnt if all did).
-__device__ __forceinline__ int xs_batch(const xs_summary &q, int start, int cnt, double &s)
+// (wave-uniform) and return the index of the first item that does not apply (cnt if all did).  Plain runs (K = 0, no
+// tie) are validated and applied together with one prefix sum; a run that holds binade crossings or a tie stops the
+// scan, is applied by itself, and the scan goes on behind it.
+__device__ __forceinline__ int xs_batch(const xs_summary &q, int start, int cnt, double &s, long long *prof = nullptr)
 {
-    const int lane = threadIdx.x & 63;
-    int32_t   E0, neg0;
-    if (!xs_binade_of(s, &E0, &neg0)) {
-        // no binade (0, subnormal, inf, nan): only empty runs may be skipped
-        const bool               active = lane >= start && lane < cnt;
-        const unsigned long long fail = __ballot(active && !(q.E < 0 && !(q.meta & XS_IRREGULAR)));
-        return fail ? (int)__builtin_ctzll(fail) : cnt;
+    const int  lane = threadIdx.x & 63;
+    const bool special = (q.meta & (XS_TIE | 0xff00)) != 0;
+    XS_PROF_ADD(9, 1);
+    for (;;) {
+        XS_PROF_ADD(8, 1);
+        int32_t E0, neg0;
+        if (!xs_binade_of(s, &E0, &neg0)) {
+            // no binade (0, subnormal, inf, nan): only empty runs may be skipped
+            const bool               active = lane >= start && lane < cnt;
+            const unsigned long long fail = __ballot(active && !xs_is_identity(q));
+            return fail ? (int)__builtin_ctzll(fail) : cnt;
+        }
+        const int64_t M = xs_mantissa(s);
+        const bool    active = lane >= start && lane < cnt;
+        const int64_t D = active && !special ? q.A : 0;
+        // Inclusive prefix over the lanes with DPP moves (no LDS crossbar round trips on this serial path).  Plain wrapping
+        // adds: the prefix of lane k involves lanes <= k only, so it is exact for every lane up to and including the first
+        // one that fails (all runs before it are valid, hence small), and nothing beyond that lane is used.
+        int64_t incl = D;
+        incl += dpp_i64<0x111, 0xf>(incl);  // row_shr:1
+        incl += dpp_i64<0x112, 0xf>(incl);  // row_shr:2
+        incl += dpp_i64<0x114, 0xf>(incl);  // row_shr:4
+        incl += dpp_i64<0x118, 0xf>(incl);  // row_shr:8   -> prefix inside each row of 16 lanes
+        incl += dpp_i64<0x142, 0xa>(incl);  // row_bcast:15 into rows 1 and 3
+        incl += dpp_i64<0x143, 0xc>(incl);  // row_bcast:31 into rows 2 and 3
+        const int64_t            excl = incl - D;
+        const bool               ok = !active || (!special && xs_applies(q, E0, neg0, M + excl));
+        const unsigned long long fail = __ballot(!ok);
+        const int                f = fail ? (int)__builtin_ctzll(fail) : cnt;
+        int64_t                  Mf = M;  // the mantissa item f meets
+        if (f > start) Mf = M + readlane_i64(incl, f - 1);
+        if (f > start) s = xs_compose(E0, neg0, Mf);
+        if (f >= cnt) return cnt;
+        const int metaf = __builtin_amdgcn_readlane(q.meta, f);
+        if ((metaf & XS_IRREGULAR) || !(metaf & (XS_TIE | 0xff00))) return f;
+        xs_summary qf;
+        qf.meta = metaf;
+        qf.E = __builtin_amdgcn_readlane(q.E, f);
+        qf.Mlo = readlane_i64(q.Mlo, f);
+        qf.Mhi = readlane_i64(q.Mhi, f);
+        if (!xs_applies(qf, E0, neg0, Mf)) return f;
+        qf.A = readlane_i64(q.A, f);
+        qf.C = readlane_i64(q.C, f);
+        s = xs_apply(qf, E0, neg0, Mf);
+        XS_PROF_ADD(7, 1);
+        start = f + 1;
+        if (start >= cnt) return cnt;
     }
-    const int64_t M = xs_mantissa(s);
-    const bool    active = lane >= start && lane < cnt;
-    const int64_t D = active ? q.D : 0;
-    // Inclusive prefix over the lanes with DPP moves (no LDS crossbar round trips on this serial path).  Plain wrapping
-    // adds: the prefix of lane k involves lanes <= k only, so it is exact for every lane up to and including the first
-    // one that fails (all runs before it are valid, hence small), and nothing beyond that lane is used.
-    int64_t incl = D;
-    incl += dpp_i64<0x111, 0xf>(incl);  // row_shr:1
-    incl += dpp_i64<0x112, 0xf>(incl);  // row_shr:2
-    incl += dpp_i64<0x114, 0xf>(incl);  // row_shr:4
-    incl += dpp_i64<0x118, 0xf>(incl);  // row_shr:8   -> prefix inside each row of 16 lanes
-    incl += dpp_i64<0x142, 0xa>(incl);  // row_bcast:15 into rows 1 and 3
-    incl += dpp_i64<0x143, 0xc>(incl);  // row_bcast:31 into rows 2 and 3
-    const int64_t excl = incl - D;
-    const bool               ok = !active || xs_applies(q, E0, neg0, xs_sat_add(M, excl));
-    const unsigned long long fail = __ballot(!ok);
-    const int                f = fail ? (int)__builtin_ctzll(fail) : cnt;
-    if (f > start) s = xs_compose(E0, neg0, M + readlane_i64(incl, f - 1));
-    return f;
 }
 
-// s + (the 128 elements of one cell: lane l holds elements 2l, 2l+1 in t0, t1), left to right.  Every lane carries the
-// same s.  The elements go through this wave's 1 KiB of LDS: the reads are broadcasts that do not depend on the
-// additions, so they run ahead of the one dependent chain (as chain_add of seq_sums, cg_kernels.h).
-__device__ __forceinline__ double xs_chain(double s, double t0, double t1, double *stage)
+// s + (the 128 elements of one cell, staged in LDS), left to right.  Every lane carries the same s.  The reads are
+// broadcasts that do not depend on the additions, so they run ahead of the one dependent chain (as chain_add of
+// seq_sums, cg_kernels.h).
+__device__ __forceinline__ double xs_chain(double s, const double *stage)
 {
-    const int lane = threadIdx.x & 63;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();  // the previous cell's reads are over
-    *reinterpret_cast<double2 *>(stage + 2 * lane) = make_double2(t0, t1);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll 2
     for (int j = 0; j < XS_CELL; j += 16) {
         double t[16];
@@ -373,196 +514,208 @@ __device__ __forceinline__ void xs_cell_terms(int slot, int64_t n, const double 
     t1 = slot ? t[1][1] : t[0][1];
 }
 
-constexpr int XS_PF_CELLS = 8;  // cells of a batch whose elements are fetched ahead (those flagged irregular)
+// ---- The driver: one workgroup of 16 waves per sum.
+// Round = up to XD_ITEMS items (group summaries; cell summaries when there is no group level).
+//   Phase 1, all waves: a wave takes every 16th batch of 64 items -- copies them into LDS, joins them into ONE summary
+//   of the batch, and for the items flagged irregular fetches what the walk will need when it gets there: the 64 cell
+//   summaries of such a group and the 128 elements of such a cell (three dependent trips to memory, taken by 16 waves
+//   at once instead of by the walk, one after the other).
+//   Phase 2, wave 0: the walk.  Batch summaries (<= 32, one per lane) are validated and applied with one prefix sum;
+//   the walk descends into a batch that does not apply, from there into a group, from there into the elements of a
+//   cell -- all of it in LDS unless a pool overflowed.
+constexpr int XD_THREADS = 1024, XD_WAVES = XD_THREADS / 64;
+constexpr int XD_ITEMS = 2048;  // items per round
+constexpr int XD_POOL = 12;     // irregular groups whose cells are staged ahead
+constexpr int XD_CHAINS = 16;   // irregular cells whose elements are staged ahead
 
-// Elements of the cells of a batch that are KNOWN to need the element-by-element path (irregular flag: tie, binade
-// change, ...), requested all at once: the serial chain of the driver is memory latency.
-struct xs_prefetch {
-    int    idx[XS_PF_CELLS];
-    double t0[XS_PF_CELLS], t1[XS_PF_CELLS];
+struct xd_shared {
+    xs_summary G[XD_ITEMS];
+    xs_summary B[XD_ITEMS / 64];
+    xs_summary pool[XD_POOL][XS_GROUP];
+    double     chain[XD_CHAINS][XS_CELL];
+    double     stage[XS_CELL];
+    int64_t    pool_gid[XD_POOL];
+    int64_t    chain_cell[XD_CHAINS];
+    int        pool_n, chain_n;
 };
 
+// elements of a cell the walk will add one by one: into the pool, if there is room
 template <int KIND>
-__device__ __forceinline__ void xs_prefetch_cells(xs_prefetch &f, int slot, int64_t n, const double *__restrict__ a,
-                                                  const double *__restrict__ b, const double *__restrict__ c, int64_t c0,
-                                                  int ccnt, const xs_summary &C)
-{
-    const int          lane = threadIdx.x & 63;
-    unsigned long long flagged = __ballot(lane < ccnt && (C.meta & XS_IRREGULAR));
-#pragma unroll
-    for (int j = 0; j < XS_PF_CELLS; ++j) {
-        f.idx[j] = flagged ? (int)__builtin_ctzll(flagged) : -1;
-        flagged &= flagged - 1;
-        f.t0[j] = f.t1[j] = 0.0;
-        if (f.idx[j] >= 0) xs_cell_terms<KIND>(slot, n, a, b, c, c0 + f.idx[j], f.t0[j], f.t1[j]);
-    }
-}
-
-// The cells [c0, c0+ccnt) of one batch (summary of cell c0+lane in C), applied to s.  A cell that fails only the range
-// check against the actual running sum (not prefetched) is fetched when it is met.
-template <int KIND>
-__device__ __forceinline__ double xs_walk_cells(double s, int slot, int64_t n, const double *__restrict__ a,
-                                                const double *__restrict__ b, const double *__restrict__ c, int64_t c0,
-                                                int ccnt, const xs_summary &C, double *stage, const xs_prefetch &f,
-                                                long long *prof = nullptr)
-{
-    int cstart = 0;
-    while (cstart < ccnt) {
-        const int cf = xs_batch(C, cstart, ccnt, s);
-        if (cf >= ccnt) break;
-        const long long tc0 = prof ? wall_clock64() : 0;
-        double t0 = 0.0, t1 = 0.0;
-        bool   have = false;
-#pragma unroll
-        for (int j = 0; j < XS_PF_CELLS; ++j)
-            if (f.idx[j] == cf) {
-                t0 = f.t0[j];
-                t1 = f.t1[j];
-                have = true;
-            }
-        if (!have) xs_cell_terms<KIND>(slot, n, a, b, c, c0 + cf, t0, t1);
-        s = xs_chain(s, t0, t1, stage);
-        if (prof) {
-            XS_PROF_ADD(2, 1);
-            XS_PROF_ADD(5, wall_clock64() - tc0 + (long long)(s != s));  // (depends on s: the clock is read after the chain)
-        }
-        cstart = cf + 1;
-    }
-    return s;
-}
-
-// Few cells (<= 4096): no group level.  The cell summaries are walked 64 at a time, two batches ahead in flight: when
-// batch k is walked, its summaries and the elements of its flagged cells arrived while batch k-1 was walked.
-template <int KIND>
-__device__ double xs_walk_flat(int slot, int64_t n, const double *__restrict__ a, const double *__restrict__ b,
-                               const double *__restrict__ c, int64_t ncells, const xs_summary *__restrict__ cells, double *stage,
-                               long long *prof = nullptr)
+__device__ __forceinline__ void xd_stage_chain(xd_shared &S, int slot, int64_t n, const double *__restrict__ a,
+                                               const double *__restrict__ b, const double *__restrict__ c, int64_t cell)
 {
     const int lane = threadIdx.x & 63;
-    cells += slot * ncells;
-    auto load = [&](int64_t c0) {
-        xs_summary q = xs_identity();
-        if (c0 + lane < ncells) q = cells[c0 + lane];
-        return q;
-    };
-    auto count = [&](int64_t c0) { return (int)(ncells - c0 < 64 ? (ncells - c0 > 0 ? ncells - c0 : 0) : 64); };
-    double      s = 0.0;
-    xs_summary  C0 = load(0), C1 = load(64);
-    xs_prefetch f0, f1;
-    xs_prefetch_cells<KIND>(f0, slot, n, a, b, c, 0, count(0), C0);
-    for (int64_t c0 = 0; c0 < ncells; c0 += 64) {
-        const xs_summary C2 = load(c0 + 128);
-        xs_prefetch_cells<KIND>(f1, slot, n, a, b, c, c0 + 64, count(c0 + 64), C1);
-        XS_PROF_ADD(0, 1);
-        s = xs_walk_cells<KIND>(s, slot, n, a, b, c, c0, count(c0), C0, stage, f0, prof);
-        C0 = C1;
-        C1 = C2;
-        f0 = f1;
-    }
-    return s;
+    int       id = 0;
+    if (lane == 0) id = atomicAdd(&S.chain_n, 1);
+    id = __builtin_amdgcn_readfirstlane(id);
+    if (id >= XD_CHAINS) return;
+    double t0, t1;
+    xs_cell_terms<KIND>(slot, n, a, b, c, cell, t0, t1);
+    if (lane == 0) S.chain_cell[id] = cell;
+    *reinterpret_cast<double2 *>(&S.chain[id][2 * lane]) = make_double2(t0, t1);
 }
 
+// s + cell, element by element (wave 0)
 template <int KIND>
-__device__ double xs_walk(int slot, int64_t n, const double *__restrict__ a, const double *__restrict__ b,
-                          const double *__restrict__ c, int64_t ncells, int64_t ngroups, const xs_summary *__restrict__ cells,
-                          const xs_summary *__restrict__ groups, double *stage, long long *prof = nullptr)
+__device__ __forceinline__ double xd_chain(xd_shared &S, double s, int slot, int64_t n, const double *__restrict__ a,
+                                           const double *__restrict__ b, const double *__restrict__ c, int64_t cell)
 {
-    const int lane = threadIdx.x & 63;
+    const int                lane = threadIdx.x & 63;
+    const int                have = S.chain_n < XD_CHAINS ? S.chain_n : XD_CHAINS;
+    const unsigned long long hit = __ballot(lane < have && S.chain_cell[lane] == cell);
+    if (hit) return xs_chain(s, S.chain[__builtin_ctzll(hit)]);
+    double t0, t1;
+    xs_cell_terms<KIND>(slot, n, a, b, c, cell, t0, t1);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();  // the previous cell's reads are over
+    *reinterpret_cast<double2 *>(S.stage + 2 * lane) = make_double2(t0, t1);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    return xs_chain(s, S.stage);
+}
+
+// the sum of slot `slot` (its result is wave 0's; call with the whole workgroup)
+template <int KIND>
+__device__ double xd_sum(xd_shared &S, int slot, int64_t n, const double *__restrict__ a, const double *__restrict__ b,
+                         const double *__restrict__ c, int64_t ncells, int64_t ngroups, const xs_summary *__restrict__ cells,
+                         const xs_summary *__restrict__ groups, long long *prof)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     cells += slot * ncells;
-    groups += slot * ngroups;
-    double s = 0.0;
-    // group summaries: three batches ahead of the one being walked (a batch is ~0.5 us of work, a miss in L2 ~2 us)
-    auto load_groups = [&](int64_t g0) {
-        xs_summary q = xs_identity();
-        if (g0 + lane < ngroups) q = groups[g0 + lane];
-        return q;
-    };
-    xs_summary Q0 = load_groups(0), Q1 = load_groups(64), Q2 = load_groups(128);
-    for (int64_t g0 = 0; g0 < ngroups; g0 += 64) {
-        const int        cnt = (int)(ngroups - g0 < 64 ? ngroups - g0 : 64);
-        const xs_summary Q = Q0;
-        Q0 = Q1;
-        Q1 = Q2;
-        Q2 = load_groups(g0 + 192);
-        // Cell summaries of the groups already known to need their cells (irregular: a binade change is predicted inside,
-        // a tie, ...): two of them are always in flight ahead of the walk, refilled as the walk passes them.
-        unsigned long long remaining = __ballot(lane < cnt && (Q.meta & XS_IRREGULAR));
-        int                pf_g[2] = {-1, -1};
-        xs_summary         pf_C[2] = {xs_identity(), xs_identity()};
-        auto refill = [&](int j) {
-            pf_g[j] = remaining ? (int)__builtin_ctzll(remaining) : -1;
-            remaining &= remaining - 1;
-            pf_C[j] = xs_identity();
-            if (pf_g[j] >= 0 && (g0 + pf_g[j]) * XS_GROUP + lane < ncells) pf_C[j] = cells[(g0 + pf_g[j]) * XS_GROUP + lane];
-        };
-        refill(0);
-        refill(1);
-        XS_PROF_ADD(0, 1);
-        int start = 0;
-        while (start < cnt) {
-            const int f = xs_batch(Q, start, cnt, s);
-            if (f >= cnt) break;
-            const long long tg0 = prof ? wall_clock64() : 0;
-            const int64_t c0 = (g0 + f) * XS_GROUP;
-            const int     ccnt = (int)(ncells - c0 < XS_GROUP ? ncells - c0 : XS_GROUP);
-            xs_summary    C = xs_identity();
-            bool          have = false;
-            remaining &= f >= 63 ? 0ull : ~((2ull << f) - 1ull);  // nothing at or before f is worth fetching any more
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                if (pf_g[j] == f) {
-                    C = pf_C[j];
-                    have = true;
+    if (groups) groups += slot * ngroups;
+    const xs_summary *items = groups ? groups : cells;
+    const int64_t     nitems = groups ? ngroups : ncells;
+    double            s = 0.0;
+    const long long   tk0 = prof ? wall_clock64() : 0;
+    for (int64_t base = 0; base < nitems; base += XD_ITEMS) {
+        const int cnt = (int)(nitems - base < XD_ITEMS ? nitems - base : XD_ITEMS), nb = (cnt + 63) / 64;
+        if (threadIdx.x == 0) S.pool_n = S.chain_n = 0;
+        __syncthreads();
+        const long long tp0 = prof ? wall_clock64() : 0;
+        // ---- phase 1
+        for (int bb = wave; bb < nb; bb += XD_WAVES) {
+            const int64_t i = base + bb * 64 + lane;
+            xs_summary    q = xs_identity();
+            if (i < nitems) q = items[i];
+            S.G[bb * 64 + lane] = q;
+            unsigned long long irr = __ballot((q.meta & XS_IRREGULAR) != 0);
+            while (irr) {
+                const int64_t it = base + bb * 64 + __builtin_ctzll(irr);
+                irr &= irr - 1;
+                if (!groups) {
+                    xd_stage_chain<KIND>(S, slot, n, a, b, c, it);
+                    continue;
                 }
-                if (pf_g[j] >= 0 && pf_g[j] <= f) refill(j);  // used, or passed without being needed
+                int id = 0;
+                if (lane == 0) id = atomicAdd(&S.pool_n, 1);
+                id = __builtin_amdgcn_readfirstlane(id);
+                if (id >= XD_POOL) continue;
+                xs_summary cq = xs_identity();
+                if (it * XS_GROUP + lane < ncells) cq = cells[it * XS_GROUP + lane];
+                if (lane == 0) S.pool_gid[id] = it;
+                S.pool[id][lane] = cq;
+                unsigned long long cirr = __ballot((cq.meta & XS_IRREGULAR) != 0);
+                while (cirr) {
+                    xd_stage_chain<KIND>(S, slot, n, a, b, c, it * XS_GROUP + __builtin_ctzll(cirr));
+                    cirr &= cirr - 1;
+                }
             }
-            if (!have && lane < ccnt) C = cells[c0 + lane];
-            xs_prefetch pf;
-            xs_prefetch_cells<KIND>(pf, slot, n, a, b, c, c0, ccnt, C);
-            s = xs_walk_cells<KIND>(s, slot, n, a, b, c, c0, ccnt, C, stage, pf, prof);
-            if (prof) {
-                XS_PROF_ADD(1, 1);
-                XS_PROF_ADD(4, wall_clock64() - tg0 + (long long)(s != s));
-            }
-            start = f + 1;
+            const xs_summary j = wave_join(q);
+            if (lane == 0) S.B[bb] = j;
         }
+        __syncthreads();
+        const long long tp1 = prof ? wall_clock64() : 0;
+        if (wave == 0) XS_PROF_ADD(4, tp1 - tp0);
+        // ---- phase 2
+        if (wave == 0) {
+            xs_summary Bq = xs_identity();
+            if (lane < nb) Bq = S.B[lane];
+            int tstart = 0;
+            while (tstart < nb) {
+                const int fb = xs_batch(Bq, tstart, nb, s, prof);
+                if (fb >= nb) break;
+                XS_PROF_ADD(0, 1);
+                const xs_summary Gq = S.G[fb * 64 + lane];
+                const int        gcnt = cnt - fb * 64 < 64 ? cnt - fb * 64 : 64;
+                int              gstart = 0;
+                while (gstart < gcnt) {
+                    const int f = xs_batch(Gq, gstart, gcnt, s, prof);
+                    if (f >= gcnt) break;
+                    const int64_t it = base + fb * 64 + f;
+                    if (!groups) {
+                        s = xd_chain<KIND>(S, s, slot, n, a, b, c, it);
+                        XS_PROF_ADD(2, 1);
+                    } else {
+                        XS_PROF_ADD(1, 1);
+                        const int                have = S.pool_n < XD_POOL ? S.pool_n : XD_POOL;
+                        const unsigned long long hit = __ballot(lane < have && S.pool_gid[lane] == it);
+                        const int64_t            c0 = it * XS_GROUP;
+                        const int                ccnt = (int)(ncells - c0 < XS_GROUP ? ncells - c0 : XS_GROUP);
+                        xs_summary               Cq = xs_identity();
+                        if (hit)
+                            Cq = S.pool[__builtin_ctzll(hit)][lane];
+                        else if (lane < ccnt)
+                            Cq = cells[c0 + lane];
+                        int cstart = 0;
+                        while (cstart < ccnt) {
+                            const int cf = xs_batch(Cq, cstart, ccnt, s, prof);
+                            if (cf >= ccnt) break;
+                            s = xd_chain<KIND>(S, s, slot, n, a, b, c, c0 + cf);
+                            XS_PROF_ADD(2, 1);
+                            cstart = cf + 1;
+                        }
+                    }
+                    gstart = f + 1;
+                }
+                tstart = fb + 1;
+            }
+            if (prof) XS_PROF_ADD(5, wall_clock64() - tp1 + (long long)(s != s));
+            if (prof) XS_PROF_ADD(10, tp0 - tk0);
+        }
+        __syncthreads();  // the next round refills what the walk read
     }
     return s;
 }
 
+// Grid = one workgroup per sum in use (KIND 2: r.r and |r|_1 at once); the workgroup that finishes last finalises like
+// seq_sums (alpha / beta / residual / done flag).  xfer: [0..1] the sums, [2] tickets (zero between launches).
 template <int KIND>
-__global__ __launch_bounds__(128) void xs_drive(int64_t n, const double *__restrict__ a, const double *__restrict__ b,
-                                               const double *__restrict__ c, int64_t ncells, int64_t ngroups,
-                                               const xs_summary *__restrict__ cells, const xs_summary *__restrict__ groups,
-                                               int mode, double *hist, int iter, double tol, int *done, double *out,
-                                               long long *prof_buf)
+__global__ __launch_bounds__(XD_THREADS) void xs_drive(int64_t n, const double *__restrict__ a, const double *__restrict__ b,
+                                                      const double *__restrict__ c, int64_t ncells, int64_t ngroups,
+                                                      const xs_summary *__restrict__ cells, const xs_summary *__restrict__ groups,
+                                                      int mode, double *hist, int iter, double tol, int *done, double *out,
+                                                      double *xfer, long long *prof_buf)
 {
     constexpr int S0 = KIND == XS_L1 ? 1 : 0, S1 = KIND == XS_DOT ? 0 : 1;
-    __shared__ double res[2];
-    __shared__ __attribute__((aligned(16))) double stage[2][XS_CELL];
-    const int wave = threadIdx.x >> 6;
-    if (threadIdx.x < 2) res[threadIdx.x] = 0.0;
-    __syncthreads();
+    __shared__ xd_shared S;
+    const int  slot = S0 + (int)blockIdx.x;
     const bool frozen = done != nullptr && mode != 3 && mode != 0 && *done != 0;
-    if (!frozen && wave >= S0 && wave <= S1) {
-        long long      *prof = wave == S0 ? prof_buf : nullptr;
-        const long long t0 = prof ? wall_clock64() : 0;
-        const double s = groups != nullptr ? xs_walk<KIND>(wave, n, a, b, c, ncells, ngroups, cells, groups, stage[wave], prof)
-                                           : xs_walk_flat<KIND>(wave, n, a, b, c, ncells, cells, stage[wave], prof);
-        if ((threadIdx.x & 63) == 0) res[wave] = s;
-        if (prof) {
-            XS_PROF_ADD(3, wall_clock64() - t0 + (long long)(s != s));
-            XS_PROF_ADD(6, 1);
-        }
+    if (frozen) return;
+    long long      *prof = slot == S0 ? prof_buf : nullptr;
+    const long long t0 = prof ? wall_clock64() : 0;
+    const double    s = xd_sum<KIND>(S, slot, n, a, b, c, ncells, ngroups, cells, groups, prof);
+    if (threadIdx.x != 0) return;
+    if (prof) {
+        XS_PROF_ADD(3, wall_clock64() - t0 + (long long)(s != s));
+        XS_PROF_ADD(6, 1);
     }
-    __syncthreads();
-    if (threadIdx.x != 0 || frozen) return;
-    const double s_dot = res[0], s_l1 = res[1];
+    double s_dot = s, s_l1 = s;
+    if constexpr (S1 > S0) {
+        // two workgroups: the second to arrive has both sums (stores and loads at agent scope around the ticket)
+        unsigned long long *tk = reinterpret_cast<unsigned long long *>(xfer + 2);
+        __hip_atomic_store(xfer + slot, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long old = __hip_atomic_fetch_add(tk, 1ull, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (old == 0) return;
+        __hip_atomic_store(tk, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_dot = __hip_atomic_load(xfer + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_l1 = __hip_atomic_load(xfer + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     if (iter == 0 && mode == 1) iter = done[2] + 1;  // as seq_sums: iteration number from the device (graph replay)
     if (iter == 0 && mode == 2) iter = done[1];
     if (mode == 0) {
-        out[0] = s_dot;
-        out[1] = s_l1;
+        out[0] = KIND == XS_L1 ? 0.0 : s_dot;
+        out[1] = KIND == XS_DOT ? 0.0 : s_l1;
     } else if (mode == 1) {
         hist[(size_t)iter * CGH_HIST + 2] = hist[(size_t)(iter - 1) * CGH_HIST + 1] / s_dot;
     } else if (mode == 2) {
@@ -605,12 +758,13 @@ int launch_all(cgh_xsum *w, bool presummed, int64_t n, const double *a, const do
         hipLaunchKernelGGL(xs_group_scan, dim3(1), dim3(256), 0, s, w->ngroups, (const double *)w->groupsum, w->gprefix);
         prefix = w->gprefix;
     }
-    const bool  flat = w->ncells <= 4096;  // few cells: no group level (xs_walk_flat)
+    const bool  flat = w->ncells <= XD_ITEMS;  // few cells: no group level
     xs_summary *grp = flat ? nullptr : w->groups;
     hipLaunchKernelGGL((xs_summarize<KIND>), dim3(flat ? 4 * ng : ng), dim3(256), 0, s, n, a, b, c, w->ncells, w->ngroups,
                        (const double *)w->cellsum, gsum, prefix, w->cells, grp);
-    hipLaunchKernelGGL((xs_drive<KIND>), dim3(1), dim3(128), 0, s, n, a, b, c, w->ncells, w->ngroups,
-                       (const xs_summary *)w->cells, (const xs_summary *)grp, mode, hist, iter, tol, done, out, g_xs_prof);
+    hipLaunchKernelGGL((xs_drive<KIND>), dim3(KIND == XS_BOTH_SAME ? 2 : 1), dim3(XD_THREADS), 0, s, n, a, b, c, w->ncells,
+                       w->ngroups, (const xs_summary *)w->cells, (const xs_summary *)grp, mode, hist, iter, tol, done, out, w->xfer,
+                       g_xs_prof);
     CGH_HIP(hipGetLastError());
     return CGH_OK;
 }
@@ -629,7 +783,12 @@ cgh_xsum *cgh_xsum_create(int64_t n)
     w->gprefix = (double *)cgh_alloc(sizeof(double) * 2 * (size_t)w->ngroups);
     w->cells = (xs_summary *)cgh_alloc(sizeof(xs_summary) * 2 * (size_t)w->ncells);
     w->groups = (xs_summary *)cgh_alloc(sizeof(xs_summary) * 2 * (size_t)w->ngroups);
-    if (!w->cellsum || !w->groupsum || !w->gprefix || !w->cells || !w->groups) {
+    w->xfer = (double *)cgh_alloc(sizeof(double) * 4);
+    if (w->xfer && hipMemset(w->xfer, 0, sizeof(double) * 4) != hipSuccess) {
+        cgh_free(w->xfer);
+        w->xfer = nullptr;
+    }
+    if (!w->cellsum || !w->groupsum || !w->gprefix || !w->cells || !w->groups || !w->xfer) {
         cgh_xsum_free(w);
         return nullptr;
     }
@@ -644,6 +803,7 @@ void cgh_xsum_free(cgh_xsum *w)
     cgh_free(w->gprefix);
     cgh_free(w->cells);
     cgh_free(w->groups);
+    cgh_free(w->xfer);
     delete w;
 }
 

@@ -18,24 +18,21 @@ double tree_sum(const double *t, int64_t n)  // any approximate sum will do for 
 
 xs_summary summarize_cell(const double *t, int64_t cnt, double predicted_start)
 {
-    xs_summary q = xs_identity();
-    int32_t    E, neg;
-    bool       zeros = true;  // a cell of zeros only is the identity whatever the prediction (xsum.hip, xs_summarize)
+    int32_t E, neg;
+    bool    zeros = true;  // a cell of zeros only is the identity whatever the prediction (xsum.hip, xs_summarize)
     for (int64_t k = 0; k < cnt; ++k) zeros = zeros && t[k] == 0.0;
-    if (zeros) return q;
-    if (!xs_binade_of(predicted_start, &E, &neg)) {
-        q.meta = XS_IRREGULAR;
-        return q;
-    }
-    for (int64_t k = 0; k < cnt; ++k) q = xs_join(q, xs_single(t[k], E, neg));
-    return q;
+    if (zeros) return xs_identity();
+    if (!xs_binade_of(predicted_start, &E, &neg)) return xs_regular(0, 0, 0, 0, 0, true);
+    // plain run, or (if the predicted mantissa would leave the binade upwards inside the cell) a run with one crossing
+    return xs_cell_summary(t, (int)cnt, E, neg, xs_mantissa(predicted_start));
 }
 
 } // namespace
 
 extern "C" {
 
-// stats[0] groups applied whole, [1] cells applied whole, [2] cells added element by element
+// stats[0] groups applied whole, [1] cells applied whole, [2] cells added element by element, [3] applied summaries that
+// held binade crossings
 double xsum_model_sum(const double *t, int64_t n, int64_t *stats)
 {
     const int64_t ncells = (n + XS_CELL - 1) / XS_CELL, ngroups = (ncells + XS_GROUP - 1) / XS_GROUP;
@@ -56,19 +53,21 @@ double xsum_model_sum(const double *t, int64_t n, int64_t *stats)
         for (int64_t c = g * XS_GROUP; c < ncells && c < (g + 1) * XS_GROUP; ++c) q = xs_join(q, cs[c]);
         gs[g] = q;
     }
-    int64_t st[3] = {0, 0, 0};
+    int64_t st[4] = {0, 0, 0, 0};
     double  s = 0.0;
     for (int64_t g = 0; g < ngroups; ++g) {
         int32_t E, neg;
         if (xs_binade_of(s, &E, &neg) && xs_applies(gs[g], E, neg, xs_mantissa(s))) {
-            s = xs_compose(E, neg, xs_mantissa(s) + gs[g].D);
+            s = xs_apply(gs[g], E, neg, xs_mantissa(s));
             ++st[0];
+            st[3] += (xs_K(gs[g]) > 0 || (gs[g].meta & XS_TIE)) && gs[g].E >= 0;
             continue;
         }
         for (int64_t c = g * XS_GROUP; c < ncells && c < (g + 1) * XS_GROUP; ++c) {
             if (xs_binade_of(s, &E, &neg) && xs_applies(cs[c], E, neg, xs_mantissa(s))) {
-                s = xs_compose(E, neg, xs_mantissa(s) + cs[c].D);
+                s = xs_apply(cs[c], E, neg, xs_mantissa(s));
                 ++st[1];
+                st[3] += (xs_K(cs[c]) > 0 || (cs[c].meta & XS_TIE)) && cs[c].E >= 0;
                 continue;
             }
             const int64_t b = c * XS_CELL, cnt = n - b < XS_CELL ? n - b : XS_CELL;
@@ -76,7 +75,7 @@ double xsum_model_sum(const double *t, int64_t n, int64_t *stats)
             ++st[2];
         }
     }
-    if (stats) stats[0] = st[0], stats[1] = st[1], stats[2] = st[2];
+    if (stats) stats[0] = st[0], stats[1] = st[1], stats[2] = st[2], stats[3] = st[3];
     return s;
 }
 

@@ -27,7 +27,7 @@ def model():
 
 def run(lib, t):
     t = np.ascontiguousarray(t, dtype=np.float64)
-    st = (C.c_int64 * 3)()
+    st = (C.c_int64 * 4)()
     p = t.ctypes.data_as(C.POINTER(C.c_double))
     got = lib.xsum_model_sum(p, t.size, st)
     want = lib.xsum_model_sequential(p, t.size)

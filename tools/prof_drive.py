@@ -22,7 +22,6 @@ for shape in ((256, 256, 256), (128, 128, 128), (400, 320, 1), (40, 40, 20)):
     L.cgh_xsum_set_prof(None)
     p = prof.to_host().view(np.int64)
     walks = max(int(p[6]), 1)
-    print("n=%9d  %7.1f us/it | per walk (%d walks): batches %.1f  groups cell-by-cell %.1f  cells element-by-element %.1f | "
-          "%.1f us total, %.1f us in such groups, %.1f us in element chains" % (
-              n, r.solve_ms / iters * 1e3, walks, p[0] / walks, p[1] / walks, p[2] / walks, p[3] / walks / 100.0,
-              p[4] / walks / 100.0, p[5] / walks / 100.0), flush=True)
+    print("n=%9d  %7.1f us/it | per walk (%d walks): batches descended into %.1f  groups cell-by-cell %.1f  cells element-by-element %.1f  "
+          "runs with a crossing or a tie applied whole %.1f | %.1f us in the driver: %.1f staging + joins, %.1f walk; xs_batch calls %.1f, scans %.1f; start-up %.1f us" % (
+              n, r.solve_ms / iters * 1e3, walks, p[0] / walks, p[1] / walks, p[2] / walks, p[7] / walks, p[3] / walks / 100.0, p[4] / walks / 100.0, p[5] / walks / 100.0, p[9] / walks, p[8] / walks, p[10] / walks / 100.0), flush=True)

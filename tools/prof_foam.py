@@ -22,5 +22,5 @@ for tag in ("2000", "8000", "32k"):
     p = prof.to_host().view(np.int64)
     walks = max(int(p[6]), 1)
     rt, _ = cga.cg_solve(A, b, x, fixed_iters=iters, strict=0)
-    print("foam %s n=%d K=%d strict %.1f us/it (throughput %.1f) | per walk (%d): batches %.1f chains %.1f | %.1f us total, %.1f us in chains" % (
-        tag, n, A.K, r.solve_ms / iters * 1e3, rt.solve_ms / iters * 1e3, walks, p[0] / walks, p[2] / walks, p[3] / walks / 100.0, p[5] / walks / 100.0), flush=True)
+    print("foam %s n=%d K=%d strict %.1f us/it (throughput %.1f) | per walk (%d): batches descended into %.1f chains %.1f crossings/ties applied whole %.1f | %.1f us in the driver: %.1f staging + joins, %.1f walk" % (
+        tag, n, A.K, r.solve_ms / iters * 1e3, rt.solve_ms / iters * 1e3, walks, p[0] / walks, p[2] / walks, p[7] / walks, p[3] / walks / 100.0, p[4] / walks / 100.0, p[5] / walks / 100.0), flush=True)
