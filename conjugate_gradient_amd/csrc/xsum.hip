@@ -63,6 +63,40 @@ __device__ __forceinline__ void xs_terms(int64_t n, const double *__restrict__ a
     }
 }
 
+// The same in two steps, so that the loads of the next pass can be in flight while this one is worked on:
+// the operands of elements i, i+1 (zeros at or beyond n), then their terms.
+template <int KIND>
+__device__ __forceinline__ void xs_raw(int64_t n, const double *__restrict__ a, const double *__restrict__ b,
+                                       const double *__restrict__ c, int64_t i, double2 &u, double2 &v)
+{
+    const double *p = KIND == XS_L1 ? c : a;
+    u = v = make_double2(0.0, 0.0);
+    if (i + 1 < n) {
+        u = *reinterpret_cast<const double2 *>(p + i);
+        if constexpr (KIND == XS_DOT) v = *reinterpret_cast<const double2 *>(b + i);
+    } else if (i < n) {
+        u.x = p[i];
+        if constexpr (KIND == XS_DOT) v.x = b[i];
+    }
+}
+template <int KIND>
+__device__ __forceinline__ void xs_raw_terms(const double2 &u, const double2 &v, double (&dot)[2], double (&l1)[2])
+{
+    dot[0] = dot[1] = l1[0] = l1[1] = 0.0;
+    if constexpr (KIND == XS_DOT) {
+        dot[0] = mul_rn(u.x, v.x);
+        dot[1] = mul_rn(u.y, v.y);
+    } else if constexpr (KIND == XS_L1) {
+        l1[0] = fabs(u.x);
+        l1[1] = fabs(u.y);
+    } else {
+        dot[0] = mul_rn(u.x, u.x);
+        dot[1] = mul_rn(u.y, u.y);
+        l1[0] = fabs(u.x);
+        l1[1] = fabs(u.y);
+    }
+}
+
 template <int KIND>
 __global__ __launch_bounds__(256) void xs_cell_sums(int64_t n, const double *__restrict__ a, const double *__restrict__ b,
                                                    const double *__restrict__ c, int64_t ncells, int64_t ngroups,
@@ -134,6 +168,14 @@ __global__ __launch_bounds__(256) void xs_group_scan(int64_t ngroups, const doub
     }
 }
 
+// v of the lane selected by a DPP control inside the row of 16 lanes (unspecified where the control has no source lane)
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ int64_t shfl_down_i64(int64_t v, int off) { return (int64_t)__shfl_down((long long)v, off, 64); }
 __device__ __forceinline__ int64_t shfl_up_i64(int64_t v, int off) { return (int64_t)__shfl_up((long long)v, off, 64); }
 __device__ __forceinline__ int64_t shfl_i64(int64_t v, int src) { return (int64_t)__shfl((long long)v, src, 64); }
@@ -188,24 +230,33 @@ __device__ __forceinline__ int64_t row_max(int64_t v)
     return v;
 }
 
-// Out of line, rolled loops over the lane's 8 elements staged in LDS (t): the rare path must not set the register
-// budget of the kernel that holds it.  Returns the summary, or one with meta = -1 if the cell has no single special
-// element.
-__device__ __noinline__ xs_summary xs_special16(const double *t, int32_t E, int32_t neg, int64_t Mt)
+// The exact summary of a cell the fast path of xs_summarize has flagged (an element of 2^45 ulps or more, an exact tie,
+// or the predicted mantissa leaves the binade): everything in 64-bit integers, the special element spelt out if there
+// is exactly one.  Two builds: rolled loops and out of line for the streaming kernel (the rare path must not set the
+// register budget of the kernel that holds it), unrolled and inline for sums of a few hundred cells, where one workgroup's
+// latency is the kernel's and a good part of the cells is flagged (the head of a sum, one crossing per doubling).
+template <int UNR>
+__device__ __forceinline__ xs_summary xs_cell16_exact_impl(const double *tl, int32_t E, int32_t neg, int64_t Mt)
 {
+    double t[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t[k] = tl[k];  // (UNR == 1: the compiler leaves them in LDS)
     const int lane = threadIdx.x & 63, sub = lane & 15, row0 = lane & 48;
-    int64_t   T = 0, dk;
-    bool      hard = false;
-#pragma unroll 1
+    int64_t   T = 0, dk, lo_l = 0, hi_l = 0;
+    bool      hard = false, tie = false;
+#pragma unroll UNR
     for (int k = 0; k < 8; ++k) {
         const int cls = xs_classify(t[k], E, neg, &dk);
         hard = hard || cls == 2;
+        tie = tie || cls == 1;
         T += cls ? 0 : dk;
+        lo_l = T < lo_l ? T : lo_l;
+        hi_l = T > hi_l ? T : hi_l;
     }
     const int64_t base = row_excl_scan(T, sub);
     int           kx = 8, ty = 0;
     int64_t       run = base;
-#pragma unroll 1
+#pragma unroll UNR
     for (int k = 0; k < 8; ++k) {
         const int cls = xs_classify(t[k], E, neg, &dk);
         if (kx == 8 && cls == 1) {
@@ -217,15 +268,18 @@ __device__ __noinline__ xs_summary xs_special16(const double *t, int32_t E, int3
         }
         run += cls ? 0 : dk;
     }
-    const unsigned hard_row = (unsigned)(__ballot(hard) >> row0) & 0xffffu;
+    const unsigned hard_row = (unsigned)(__ballot(hard) >> row0) & 0xffffu, tie_row = (unsigned)(__ballot(tie) >> row0) & 0xffffu;
     const unsigned spec_row = (unsigned)(__ballot(kx < 8) >> row0) & 0xffffu;
     bool           valid = !hard_row && spec_row;
+    // the plain summary: what the cell is if it has no (single) special element
+    const xs_summary plain = xs_regular(shfl_i64(base + T, row0 + 15), row_min(base + lo_l), row_max(base + hi_l), E, neg,
+                                        hard_row || tie_row);
     const int      lstar = spec_row ? (int)__builtin_ctz(spec_row) : 0, src = row0 + lstar;
     const int      kstar = __shfl(kx, src, 64), type = __shfl(ty, src, 64);
     // part 1: everything before the special element, in binade E
     int64_t lo1 = 0, hi1 = 0;
     run = base;
-#pragma unroll 1
+#pragma unroll UNR
     for (int k = 0; k < 8; ++k)
         if (sub < lstar || (sub == lstar && k < kstar)) {
             xs_classify(t[k], E, neg, &dk);  // (nothing before the first special element is one)
@@ -237,7 +291,13 @@ __device__ __noinline__ xs_summary xs_special16(const double *t, int32_t E, int3
     lo1 = row_min(lo1);
     hi1 = row_max(hi1);
     // the special element
-    const double  ts = t[kstar & 7];
+    double ts = 0.0;
+    if constexpr (UNR == 1) {
+        ts = tl[kstar & 7];
+    } else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) ts = k == kstar ? t[k] : ts;
+    }
     const double  tau = ldexp(neg ? -ts : ts, 1075 - E), cfl = floor(tau);
     const int64_t c = shfl_i64((int64_t)cfl, src);
     const int     whole = __shfl((int)(tau == cfl), src, 64);
@@ -246,7 +306,7 @@ __device__ __noinline__ xs_summary xs_special16(const double *t, int32_t E, int3
     const int32_t E2 = type == 2 ? E + 1 : E;
     int64_t       T2 = 0;
     bool          bad2 = false;
-#pragma unroll 1
+#pragma unroll UNR
     for (int k = 0; k < 8; ++k)
         if (sub > lstar || (sub == lstar && k > kstar)) {
             if (xs_classify(t[k], E2, neg, &dk)) bad2 = true, dk = 0;
@@ -256,7 +316,7 @@ __device__ __noinline__ xs_summary xs_special16(const double *t, int32_t E, int3
     const int64_t D2 = shfl_i64(base2 + T2, row0 + 15);
     int64_t       lo2 = 0, hi2 = 0;
     run = base2;
-#pragma unroll 1
+#pragma unroll UNR
     for (int k = 0; k < 8; ++k)
         if (sub > lstar || (sub == lstar && k > kstar)) {
             if (xs_classify(t[k], E2, neg, &dk)) dk = 0;
@@ -267,9 +327,8 @@ __device__ __noinline__ xs_summary xs_special16(const double *t, int32_t E, int3
     lo2 = row_min(lo2);
     hi2 = row_max(hi2);
     if ((unsigned)(__ballot(bad2) >> row0) & 0xffffu) valid = false;  // a second special element
-    xs_summary q = type == 2 ? xs_crossing(P, lo1, hi1, c, D2, lo2, hi2, E, neg, false) : xs_tie(P, lo1, hi1, c, D2, lo2, hi2, E, neg, false);
-    if (!valid) q.meta = -1;
-    return q;
+    if (!valid) return plain;
+    return type == 2 ? xs_crossing(P, lo1, hi1, c, D2, lo2, hi2, E, neg, false) : xs_tie(P, lo1, hi1, c, D2, lo2, hi2, E, neg, false);
 }
 
 // terms of the 8 consecutive elements i .. i+7 (i a multiple of 8) for the slots in use
@@ -288,10 +347,15 @@ __device__ __forceinline__ void xs_terms8(int64_t n, const double *__restrict__ 
     }
 }
 
+__device__ __noinline__ xs_summary xs_cell16_exact(const double *t, int32_t E, int32_t neg, int64_t Mt)
+{
+    return xs_cell16_exact_impl<1>(t, E, neg, Mt);
+}
+
 // One workgroup per group.  16 lanes share a cell (8 consecutive elements each: a short serial prefix in registers,
 // then a 4-step tree inside the 16 lanes), so a wave summarises 4 cells at a time and the workgroup 16.  Inside a
 // cell no saturation is needed: 128 elements of |d| < 2^52 stay below 2^59.
-template <int KIND>
+template <int KIND, bool FLAT>
 __global__ __launch_bounds__(256) void xs_summarize(int64_t n, const double *__restrict__ a, const double *__restrict__ b,
                                                    const double *__restrict__ c, int64_t ncells, int64_t ngroups,
                                                    const double *__restrict__ cellsum, const double *__restrict__ groupsum,
@@ -302,11 +366,12 @@ __global__ __launch_bounds__(256) void xs_summarize(int64_t n, const double *__r
     __shared__ double     start[2][XS_GROUP];  // predicted running sum at the start of each cell
     __shared__ xs_summary sm[2][XS_GROUP];
     __shared__ double     red[4];
-    __shared__ double     spec[256][9];  // a lane's 8 elements for xs_special16 (rows of 9: no bank conflicts)
+    constexpr int XS_TR = 4 * 64 * 10;  // doubles per slot: 4 waves x 64 rows of 8 terms (+2 of padding)
+    __shared__ __attribute__((aligned(16))) double tr[S1 - S0 + 1][4][64 * 10];
     const int     lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // groups == NULL ("flat", few cells): four workgroups per group, one pass of 16 cells each, no group summary --
     // the whole problem is then a handful of workgroups, and their serial depth is what counts
-    const bool    flat = groups == nullptr;
+    constexpr bool flat = FLAT;  // (groups == NULL)
     const int64_t g = flat ? blockIdx.x >> 2 : blockIdx.x;
     // approximate sum of everything before this group: from the scan kernel, or (few groups) summed here
     double before[2] = {0.0, 0.0};
@@ -329,59 +394,106 @@ __global__ __launch_bounds__(256) void xs_summarize(int64_t n, const double *__r
     __syncthreads();
     const int sub = threadIdx.x & 15;  // position inside the cell's 16 lanes
     const int pass_lo = flat ? (int)(blockIdx.x & 3) : 0, pass_hi = flat ? pass_lo + 1 : 4;
+    // Loads are coalesced -- load j of a lane fetches elements 32 j + 2 sub, + 1 of its cell, so 16 lanes read 256
+    // contiguous bytes (8 consecutive elements per lane, the layout the scan wants, made every load touch 64 different
+    // lines: 3.8 TB/s at best) -- and the terms go through LDS to reach the lane that scans them: lane r of the cell owns
+    // elements 8 r .. 8 r + 7, rows of 10 doubles keep the 16-byte accesses conflict-free.  The next pass's loads are
+    // issued before this pass is worked on.
+    double *const mine = tr[0][wave] + (threadIdx.x & 48) * 10;  // this cell's 16 rows (slot 0)
+    double2       u[4], v[4];
+    auto fetch = [&](int pass) {
+        const int64_t cell = g * XS_GROUP + pass * 16 + (threadIdx.x >> 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) xs_raw<KIND>(cell < ncells ? n : 0, a, b, c, cell * XS_CELL + 32 * j + 2 * sub, u[j], v[j]);
+    };
+    fetch(pass_lo);
 #pragma unroll 1
     for (int pass = pass_lo; pass < pass_hi; ++pass) {
         const int     ci = pass * 16 + (threadIdx.x >> 4);
         const int64_t cell = g * XS_GROUP + ci;
         double        t[2][8];
-        xs_terms8<KIND>(cell < ncells ? n : 0, a, b, c, cell * XS_CELL + 8 * sub, t);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();  // the previous pass's reads of the rows are over
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            double d[2], l[2];
+            xs_raw_terms<KIND>(u[j], v[j], d, l);
+            double *dst = mine + (4 * j + (sub >> 2)) * 10 + 2 * (sub & 3);
+            if constexpr (S0 == 0) *reinterpret_cast<double2 *>(dst) = make_double2(d[0], d[1]);
+            if constexpr (S1 == 1) *reinterpret_cast<double2 *>(dst + (S1 - S0) * XS_TR) = make_double2(l[0], l[1]);
+        }
+        if (pass + 1 < pass_hi) fetch(pass + 1);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int slot = S0; slot <= S1; ++slot)
+#pragma unroll
+            for (int k = 0; k < 8; k += 2) {
+                const double2 w = *reinterpret_cast<const double2 *>(mine + (slot - S0) * XS_TR + sub * 10 + k);
+                t[slot][k] = w.x;
+                t[slot][k + 1] = w.y;
+            }
 #pragma unroll
         for (int slot = S0; slot <= S1; ++slot) {
             int32_t    E, neg;
             const bool usable = xs_binade_of(start[slot][ci], &E, &neg);  // else: predicted 0 / subnormal / non-finite
-            bool       bad = !usable;
-            int64_t    D = 0, lo = 0, hi = 0;
+            // Fast path: the movements d = rint(tau) are added up as doubles.  While every |tau| < 2^45 all partial sums
+            // of the cell's 128 elements are integers below 2^52, hence exact, and a double add / min / max is one
+            // instruction where the 64-bit integer ones are several.  A cell with a larger element, an exact tie, or whose
+            // predicted mantissa leaves the binade is redone exactly, in integers, by xs_cell16_exact.
+            int             flag = 0, zeros = 1;
+            double          Dd = 0.0, lod = 0.0, hid = 0.0;
+            const int       sh = 1075 - (usable ? E : 1075);
+            const long long flip = (long long)(neg & 1) << 63;  // tau = sigma * t * 2^sh: the sign goes in with one xor
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-                const int64_t d = xs_element(t[slot][k], usable ? E : 1075, neg, &bad);
-                D += d;
-                lo = D < lo ? D : lo;
-                hi = D > hi ? D : hi;
+                const double x = t[slot][k];
+                zeros &= (int)(x == 0.0);
+                const double tau = ldexp(__longlong_as_double(__double_as_longlong(x) ^ flip), sh);
+                const double d = rint(tau);
+                // 2^45 (also NaN, inf); exact tie.  (Bitwise on purpose: no branches around single instructions.)
+                flag |= (int)!(fabs(tau) < 35184372088832.0) | (int)(fabs(tau - d) == 0.5);
+                Dd += d;
+                lod = fmin(lod, Dd);
+                hid = fmax(hid, Dd);
             }
-#pragma unroll
-            for (int off = 1; off < 16; off <<= 1) {
-                const int64_t oD = shfl_down_i64(D, off), olo = shfl_down_i64(lo, off), ohi = shfl_down_i64(hi, off);
-                if (sub + off < 16) {
-                    const int64_t blo = D + olo, bhi = D + ohi;
-                    lo = lo < blo ? lo : blo;
-                    hi = hi > bhi ? hi : bhi;
-                    D += oD;
-                }
-            }
-            const unsigned long long bad_lanes = __ballot(bad);
+            // join over the cell's 16 lanes (one DPP row): lane i takes lane i + off, valid where that lane exists
+#define XS_ROW_STEP(CTRL, OFF)                                                                                   \
+    {                                                                                                            \
+        const double oD = dpp_f64<CTRL>(Dd), olo = dpp_f64<CTRL>(lod), ohi = dpp_f64<CTRL>(hid);                 \
+        if (sub + OFF < 16) {                                                                                    \
+            lod = fmin(lod, Dd + olo);                                                                           \
+            hid = fmax(hid, Dd + ohi);                                                                           \
+            Dd += oD;                                                                                            \
+        }                                                                                                        \
+    }
+            XS_ROW_STEP(0x101, 1)  // row_shl:1
+            XS_ROW_STEP(0x102, 2)
+            XS_ROW_STEP(0x104, 4)
+            XS_ROW_STEP(0x108, 8)
+#undef XS_ROW_STEP
+            const bool cell_flag = ((__ballot(flag != 0) >> (lane & 48)) & 0xffffull) != 0;
             // A cell of zeros only leaves any running sum as it is (s + (+-0) = s; the walk starts at +0 and never holds
             // -0), whatever binade was predicted -- and none can be predicted while everything before it is zero too.
             // CG on a right-hand side with small support (the OpenFOAM systems) keeps such prefixes for hundreds of
             // iterations: without this every cell of them went element by element (foam-32k: 158 of 250 cells).
-            bool zeros = true;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) zeros = zeros && t[slot][k] == 0.0;
-            const unsigned long long zero_lanes = __ballot(zeros);
-            const bool               cell_is_zero = ((zero_lanes >> (lane & 48)) & 0xffffull) == 0xffffull;
-            const bool               cell_bad = ((bad_lanes >> (lane & 48)) & 0xffffull) != 0;
-            xs_summary               q = xs_identity();
-            if (cell < ncells && !cell_is_zero) q = xs_regular(D, lo, hi, usable ? E : 0, neg, cell_bad);
-            // One special element (an exact tie, or the element that takes the predicted mantissa into the next binade):
-            // the plain summary above cannot apply, the summary with that element spelt out can (xsum.h).  Whole waves
-            // enter; ~ln(n) ties and ~log2(n) crossings per sum, so almost none do.
+            const bool cell_is_zero = ((__ballot(zeros != 0) >> (lane & 48)) & 0xffffull) == 0xffffull;
+            xs_summary q = xs_identity();
+            if (cell < ncells && !cell_is_zero) {
+                if (!usable)
+                    q = xs_regular(0, 0, 0, 0, 0, true);  // predicted 0 / subnormal / non-finite: element by element
+                else if (!cell_flag)
+                    q = xs_regular((int64_t)Dd, (int64_t)lod, (int64_t)hid, E, neg, false);  // (exact; sub == 0 has them)
+            }
             const int64_t Mt = xs_mantissa(start[slot][ci]);
-            bool          want = cell < ncells && !cell_is_zero && usable && (cell_bad || Mt > q.Mhi);  // (sub == 0 knows)
-            want = __shfl((int)want, lane & 48, 64) != 0;
-            if (__ballot(want)) {
-#pragma unroll
-                for (int k = 0; k < 8; ++k) spec[threadIdx.x][k] = t[slot][k];
-                const xs_summary sp = xs_special16(spec[threadIdx.x], E, neg, Mt);
-                if (want && sp.meta != -1) q = sp;
+            bool          want = cell < ncells && !cell_is_zero && usable && (cell_flag || Mt > q.Mhi);  // (sub == 0 knows)
+            const unsigned long long want_rows = __ballot(want && sub == 0);
+            want = (want_rows >> (lane & 48)) & 1;
+            if (want_rows) {  // whole waves enter; ~ln(n) ties and ~log2(n) crossings per sum, so almost none do
+                const double    *row = mine + (slot - S0) * XS_TR + sub * 10;
+                const xs_summary ex = FLAT ? xs_cell16_exact_impl<8>(row, E, neg, Mt) : xs_cell16_exact(row, E, neg, Mt);
+                if (want) q = ex;
             }
             if (sub == 0) {
                 if (cell < ncells) cells[slot * ncells + cell] = q;
@@ -428,43 +540,49 @@ __device__ __forceinline__ int64_t readlane_i64(int64_t v, int k)
     return (int64_t)(((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo);
 }
 
-// Items [start, cnt) of a batch (one summary per lane): apply the longest valid prefix to the running sum s
-// (wave-uniform) and return the index of the first item that does not apply (cnt if all did).  Plain runs (K = 0, no
-// tie) are validated and applied together with one prefix sum; a run that holds binade crossings or a tie stops the
-// scan, is applied by itself, and the scan goes on behind it.
-__device__ __forceinline__ int xs_batch(const xs_summary &q, int start, int cnt, double &s, long long *prof = nullptr)
+// Inclusive prefix over the lanes of the movements of a batch's plain runs (K = 0, no tie, not irregular; the others
+// count 0), with DPP moves (no LDS crossbar round trips on the serial path).  It does not depend on the running sum, so
+// one scan serves every stop of the walk inside the batch.  Plain wrapping adds: differences over a stretch of valid
+// runs are exact, which is all that is ever used.
+__device__ __forceinline__ bool xs_plain(const xs_summary &q) { return (q.meta & (XS_IRREGULAR | XS_TIE | 0xff00)) == 0; }
+__device__ __forceinline__ int64_t xs_scan(const xs_summary &q, int cnt)
 {
-    const int  lane = threadIdx.x & 63;
-    const bool special = (q.meta & (XS_TIE | 0xff00)) != 0;
+    int64_t incl = (int)(threadIdx.x & 63) < cnt && xs_plain(q) ? q.A : 0;
+    incl += dpp_i64<0x111, 0xf>(incl);  // row_shr:1
+    incl += dpp_i64<0x112, 0xf>(incl);  // row_shr:2
+    incl += dpp_i64<0x114, 0xf>(incl);  // row_shr:4
+    incl += dpp_i64<0x118, 0xf>(incl);  // row_shr:8   -> prefix inside each row of 16 lanes
+    incl += dpp_i64<0x142, 0xa>(incl);  // row_bcast:15 into rows 1 and 3
+    incl += dpp_i64<0x143, 0xc>(incl);  // row_bcast:31 into rows 2 and 3
+    return incl;
+}
+
+// Items [start, cnt) of a batch (one summary per lane, incl = xs_scan of the batch): apply the longest valid prefix
+// to the running sum s (wave-uniform) and return the index of the first item that does not apply (cnt if all did).
+// Plain runs are validated and applied together; a run that holds binade crossings or a tie stops the stretch, is
+// applied by itself, and the next stretch starts behind it.
+__device__ __forceinline__ int xs_batch(const xs_summary &q, int64_t incl, int start, int cnt, double &s, long long *prof = nullptr)
+{
+    const int     lane = threadIdx.x & 63;
+    const bool    plain = xs_plain(q);
+    const int64_t excl = incl - (plain ? q.A : 0);
     XS_PROF_ADD(9, 1);
     for (;;) {
         XS_PROF_ADD(8, 1);
-        int32_t E0, neg0;
+        int32_t    E0, neg0;
+        const bool active = lane >= start && lane < cnt;
         if (!xs_binade_of(s, &E0, &neg0)) {
             // no binade (0, subnormal, inf, nan): only empty runs may be skipped
-            const bool               active = lane >= start && lane < cnt;
             const unsigned long long fail = __ballot(active && !xs_is_identity(q));
             return fail ? (int)__builtin_ctzll(fail) : cnt;
         }
-        const int64_t M = xs_mantissa(s);
-        const bool    active = lane >= start && lane < cnt;
-        const int64_t D = active && !special ? q.A : 0;
-        // Inclusive prefix over the lanes with DPP moves (no LDS crossbar round trips on this serial path).  Plain wrapping
-        // adds: the prefix of lane k involves lanes <= k only, so it is exact for every lane up to and including the first
-        // one that fails (all runs before it are valid, hence small), and nothing beyond that lane is used.
-        int64_t incl = D;
-        incl += dpp_i64<0x111, 0xf>(incl);  // row_shr:1
-        incl += dpp_i64<0x112, 0xf>(incl);  // row_shr:2
-        incl += dpp_i64<0x114, 0xf>(incl);  // row_shr:4
-        incl += dpp_i64<0x118, 0xf>(incl);  // row_shr:8   -> prefix inside each row of 16 lanes
-        incl += dpp_i64<0x142, 0xa>(incl);  // row_bcast:15 into rows 1 and 3
-        incl += dpp_i64<0x143, 0xc>(incl);  // row_bcast:31 into rows 2 and 3
-        const int64_t            excl = incl - D;
-        const bool               ok = !active || (!special && xs_applies(q, E0, neg0, M + excl));
+        const int64_t            M = xs_mantissa(s);
+        const int64_t            base = start > 0 ? readlane_i64(incl, start - 1) : 0;  // (lanes before `start` hold 0 or plain runs)
+        const bool               ok = !active || (plain && xs_applies(q, E0, neg0, M + (excl - base)));
         const unsigned long long fail = __ballot(!ok);
         const int                f = fail ? (int)__builtin_ctzll(fail) : cnt;
         int64_t                  Mf = M;  // the mantissa item f meets
-        if (f > start) Mf = M + readlane_i64(incl, f - 1);
+        if (f > start) Mf = M + (readlane_i64(incl, f - 1) - base);
         if (f > start) s = xs_compose(E0, neg0, Mf);
         if (f >= cnt) return cnt;
         const int metaf = __builtin_amdgcn_readlane(q.meta, f);
@@ -514,6 +632,16 @@ __device__ __forceinline__ void xs_cell_terms(int slot, int64_t n, const double 
     t1 = slot ? t[1][1] : t[0][1];
 }
 
+// trace of one walk (profile buffer words 16..): (event code, 100 MHz tick) pairs, plain stores nobody waits for
+#define XS_TRACE(code)                                                                   \
+    do {                                                                                 \
+        if (prof != nullptr && (threadIdx.x & 63) == 0 && ntrace < 240) {                \
+            prof[16 + 2 * ntrace] = (code);                                              \
+            prof[17 + 2 * ntrace] = wall_clock64() - tk0;                                \
+        }                                                                                \
+        ++ntrace;                                                                        \
+    } while (0)
+
 // ---- The driver: one workgroup of 16 waves per sum.
 // Round = up to XD_ITEMS items (group summaries; cell summaries when there is no group level).
 //   Phase 1, all waves: a wave takes every 16th batch of 64 items -- copies them into LDS, joins them into ONE summary
@@ -527,6 +655,7 @@ constexpr int XD_THREADS = 1024, XD_WAVES = XD_THREADS / 64;
 constexpr int XD_ITEMS = 2048;  // items per round
 constexpr int XD_POOL = 12;     // irregular groups whose cells are staged ahead
 constexpr int XD_CHAINS = 16;   // irregular cells whose elements are staged ahead
+constexpr int XD_DIRECT = 6;    // up to this many batches the walk takes them directly (no batch summaries)
 
 struct xd_shared {
     xs_summary G[XD_ITEMS];
@@ -588,13 +717,15 @@ __device__ double xd_sum(xd_shared &S, int slot, int64_t n, const double *__rest
     const int64_t     nitems = groups ? ngroups : ncells;
     double            s = 0.0;
     const long long   tk0 = prof ? wall_clock64() : 0;
+    int               ntrace = 0;
     for (int64_t base = 0; base < nitems; base += XD_ITEMS) {
         const int cnt = (int)(nitems - base < XD_ITEMS ? nitems - base : XD_ITEMS), nb = (cnt + 63) / 64;
         if (threadIdx.x == 0) S.pool_n = S.chain_n = 0;
         __syncthreads();
         const long long tp0 = prof ? wall_clock64() : 0;
         // ---- phase 1
-        for (int bb = wave; bb < nb; bb += XD_WAVES) {
+        const bool top = nb > XD_DIRECT;  // few batches: the walk takes them one by one, nobody joins them
+        for (int bb = wave; bb < nb; bb += (int)(blockDim.x >> 6)) {
             const int64_t i = base + bb * 64 + lane;
             xs_summary    q = xs_identity();
             if (i < nitems) q = items[i];
@@ -621,26 +752,33 @@ __device__ double xd_sum(xd_shared &S, int slot, int64_t n, const double *__rest
                     cirr &= cirr - 1;
                 }
             }
-            const xs_summary j = wave_join(q);
-            if (lane == 0) S.B[bb] = j;
+            if (top) {
+                const xs_summary j = wave_join(q);
+                if (lane == 0) S.B[bb] = j;
+            }
         }
         __syncthreads();
         const long long tp1 = prof ? wall_clock64() : 0;
         if (wave == 0) XS_PROF_ADD(4, tp1 - tp0);
+        XS_TRACE(100);
         // ---- phase 2
         if (wave == 0) {
             xs_summary Bq = xs_identity();
-            if (lane < nb) Bq = S.B[lane];
-            int tstart = 0;
+            if (top && lane < nb) Bq = S.B[lane];
+            const int64_t Binc = top ? xs_scan(Bq, nb) : 0;
+            int           tstart = 0;
             while (tstart < nb) {
-                const int fb = xs_batch(Bq, tstart, nb, s, prof);
+                const int fb = top ? xs_batch(Bq, Binc, tstart, nb, s, prof) : tstart;
+                XS_TRACE(1000 + fb);
                 if (fb >= nb) break;
                 XS_PROF_ADD(0, 1);
                 const xs_summary Gq = S.G[fb * 64 + lane];
                 const int        gcnt = cnt - fb * 64 < 64 ? cnt - fb * 64 : 64;
+                const int64_t    Ginc = xs_scan(Gq, gcnt);
                 int              gstart = 0;
                 while (gstart < gcnt) {
-                    const int f = xs_batch(Gq, gstart, gcnt, s, prof);
+                    const int f = xs_batch(Gq, Ginc, gstart, gcnt, s, prof);
+                    XS_TRACE(2000 + f);
                     if (f >= gcnt) break;
                     const int64_t it = base + fb * 64 + f;
                     if (!groups) {
@@ -653,16 +791,20 @@ __device__ double xd_sum(xd_shared &S, int slot, int64_t n, const double *__rest
                         const int64_t            c0 = it * XS_GROUP;
                         const int                ccnt = (int)(ncells - c0 < XS_GROUP ? ncells - c0 : XS_GROUP);
                         xs_summary               Cq = xs_identity();
+                        XS_TRACE(hit ? 5001 : 5000);
                         if (hit)
                             Cq = S.pool[__builtin_ctzll(hit)][lane];
                         else if (lane < ccnt)
                             Cq = cells[c0 + lane];
-                        int cstart = 0;
+                        const int64_t Cinc = xs_scan(Cq, ccnt);
+                        int           cstart = 0;
                         while (cstart < ccnt) {
-                            const int cf = xs_batch(Cq, cstart, ccnt, s, prof);
+                            const int cf = xs_batch(Cq, Cinc, cstart, ccnt, s, prof);
+                            XS_TRACE(3000 + cf);
                             if (cf >= ccnt) break;
                             s = xd_chain<KIND>(S, s, slot, n, a, b, c, c0 + cf);
                             XS_PROF_ADD(2, 1);
+                            XS_TRACE(4000 + (int)(s != s));
                             cstart = cf + 1;
                         }
                     }
@@ -670,6 +812,7 @@ __device__ double xd_sum(xd_shared &S, int slot, int64_t n, const double *__rest
                 }
                 tstart = fb + 1;
             }
+            XS_TRACE(9000 + (int)(s != s));
             if (prof) XS_PROF_ADD(5, wall_clock64() - tp1 + (long long)(s != s));
             if (prof) XS_PROF_ADD(10, tp0 - tk0);
         }
@@ -760,9 +903,15 @@ int launch_all(cgh_xsum *w, bool presummed, int64_t n, const double *a, const do
     }
     const bool  flat = w->ncells <= XD_ITEMS;  // few cells: no group level
     xs_summary *grp = flat ? nullptr : w->groups;
-    hipLaunchKernelGGL((xs_summarize<KIND>), dim3(flat ? 4 * ng : ng), dim3(256), 0, s, n, a, b, c, w->ncells, w->ngroups,
-                       (const double *)w->cellsum, gsum, prefix, w->cells, grp);
-    hipLaunchKernelGGL((xs_drive<KIND>), dim3(KIND == XS_BOTH_SAME ? 2 : 1), dim3(XD_THREADS), 0, s, n, a, b, c, w->ncells,
+    if (flat)
+        hipLaunchKernelGGL((xs_summarize<KIND, true>), dim3(4 * ng), dim3(256), 0, s, n, a, b, c, w->ncells, w->ngroups,
+                           (const double *)w->cellsum, gsum, prefix, w->cells, grp);
+    else
+        hipLaunchKernelGGL((xs_summarize<KIND, false>), dim3(ng), dim3(256), 0, s, n, a, b, c, w->ncells, w->ngroups,
+                           (const double *)w->cellsum, gsum, prefix, w->cells, grp);
+    const int64_t nbatch = ((flat ? w->ncells : w->ngroups) + 63) / 64;
+    const unsigned dthreads = nbatch >= XD_WAVES ? XD_THREADS : 64u * (unsigned)(nbatch < 1 ? 1 : nbatch);
+    hipLaunchKernelGGL((xs_drive<KIND>), dim3(KIND == XS_BOTH_SAME ? 2 : 1), dim3(dthreads), 0, s, n, a, b, c, w->ncells,
                        w->ngroups, (const xs_summary *)w->cells, (const xs_summary *)grp, mode, hist, iter, tol, done, out, w->xfer,
                        g_xs_prof);
     CGH_HIP(hipGetLastError());
