@@ -136,6 +136,7 @@ def lib():
     L.cgh_dist_width.argtypes = [vp]
     L.cgh_dist_download_local.argtypes = [vp, dp, dp, ip]
     L.cgh_dist_start.argtypes = [vp, vp, vp, C.c_double, C.c_int]
+    L.cgh_dist_set_strict.argtypes = [vp, C.c_int]
     L.cgh_dist_iterate.argtypes = [vp, C.c_int, C.c_int]
     L.cgh_dist_poll.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.cgh_dist_history.argtypes = [vp, C.c_int, C.c_int, dp]
@@ -434,8 +435,9 @@ class DistRank:
         """one-GPU timing harness: this inner slab becomes its own two neighbours (cgh_dist_loopback)"""
         check(lib().cgh_dist_loopback(self.h), "cgh_dist_loopback")
 
-    def start(self, b, x, tol, capacity):
+    def start(self, b, x, tol, capacity, strict=0):
         self._keep = (b, x)
+        check(lib().cgh_dist_set_strict(self.h, int(strict)), "cgh_dist_set_strict")
         check(lib().cgh_dist_start(self.h, b.ptr, x.ptr, tol, capacity), "cgh_dist_start")
 
     def iterate(self, count, time_kernels=0):

@@ -173,6 +173,10 @@ void      cgh_xsum_free(cgh_xsum *w);
 // were already written to cgh_xsum_cellsums() by the kernel that produced the vector; else a sweep computes them.
 int cgh_xsum_launch(cgh_xsum *w, int64_t n, const double *a, const double *b, const double *c, int mode, double *hist,
                     int iter, double tol, int *done, double *out, hipStream_t s, bool presummed = false);
+// a vector spread over several ranks: each rank's part in turn (s_in -> s_out, device), then the verdict on every rank
+int cgh_xsum_launch_part(cgh_xsum *w, int64_t n, const double *a, const double *b, const double *c, const double *s_in,
+                         double *s_out, const int *done, hipStream_t s, bool presummed);
+int cgh_xsum_finalize(const double *sums, int mode, double *hist, int iter, double tol, int *done, hipStream_t s);
 double *cgh_xsum_cellsums(cgh_xsum *w);
 int64_t cgh_xsum_cells(const cgh_xsum *w);
 

@@ -239,6 +239,11 @@ struct cgh_dist {
     int      pushed_iter = 0;                      // the exchange dist_update_xp has already pushed
     bool     ll_spmv = false;                      // the boundary SpMV reads the deposit itself (vector path)
     int64_t  halo_refs = -1;                       // stored entries with a halo column (counted at the first solve)
+    // bit-identical mode (cgh_dist_set_strict): the dots and the norm are the reference's left-to-right sums over the
+    // GLOBAL vector -- order-exact sums (xsum.hip) chained through the ranks in rank order
+    bool      strict = false;
+    cgh_xsum *xs = nullptr;                        // this rank's part of the sums
+    double   *chain = nullptr;                     // [0..1] running exact sums as they travel, [2..3] this rank's contribution, [4..5] zeros
 };
 
 namespace {
@@ -258,6 +263,11 @@ void free_solver_state(cgh_dist *d)
     cgh_free(d->done);
     cgh_free(d->d_locals);
     cgh_free(d->d_outs);
+    cgh_free(d->chain);
+    cgh_xsum_free(d->xs);
+
+    d->chain = nullptr;
+    d->xs = nullptr;
     d->p = d->r = d->Ap = d->partA = d->partB = d->hist = d->gs_local = d->gs = nullptr;
     d->done = nullptr;
     d->d_locals = d->d_outs = nullptr;
@@ -624,6 +634,43 @@ static void auto_connect_halo(cgh_dist *d)
     if (v != 1.0) halo_release(d);  // somebody could not: everybody keeps the RCCL send/recv
 }
 
+// ------------------------------------------------------------------------------------------ bit-identical mode
+// One of the reference's sums over a vector spread over the ranks (vec_dot / vec_l1norm, src/vec.c:67-85 there): rank 0's
+// rows come first, so rank q may only start when the exact running sum of ranks < q is known.  Round q: rank q
+// summarises its part (binades predicted from the exact incoming sum) and walks it from that sum; everybody else
+// contributes zeros; one all-reduce of two doubles (s + 0 + ... + 0 = s exactly) hands the running sums to all ranks.
+// After the last round every rank holds the same totals and finalises for itself.  Serial in the number of ranks by
+// construction: this mode is for verification against the reference, not for speed.
+// `sum` = which sum of the iteration (0: p.Ap or the initial residual, 1: r.r and |r|_1)
+static int strict_chain(cgh_dist *d, const double *a, const double *b, const double *c, int mode, int iter, int sum, bool presummed,
+                        hipStream_t s)
+{
+    double *run = d->chain, *mine = d->chain + 2, *zeros = d->chain + 4;
+    const int  N = d->nranks;
+    const bool frozen_check = mode != 3;
+    CGH_HIP(hipMemsetAsync(run, 0, sizeof(double) * 2, s));
+    for (int q = 0; q < N; ++q) {
+        if (q == d->rank) {
+            const int rc = cgh_xsum_launch_part(d->xs, d->n_loc, a, b, c, run, mine, frozen_check ? d->done : nullptr, s, presummed);
+            if (rc) return rc;
+        }
+        const double *contrib = q == d->rank ? mine : zeros;
+        if (g_rccl.p2p) {
+            cgh_link L;
+            const int rc = cgh_p2p_link(&L);
+            if (rc) return rc;
+            hipLaunchKernelGGL(chain_round, dim3(1), dim3(CGH_BLOCK), 0, s, L, contrib, run, (const int *)d->done, frozen_check ? 1 : 0,
+                               d->epoch, ((unsigned)iter * 2u + (unsigned)sum) * (unsigned)N + (unsigned)q);
+        } else if (N > 1) {
+            CGH_NCCL(g_rccl.AllReduce(contrib, run, 2, ncclDouble, ncclSum, g_rccl.comm, s));
+        } else {
+            CGH_HIP(hipMemcpyAsync(run, contrib, sizeof(double) * 2, hipMemcpyDeviceToDevice, s));
+        }
+    }
+    CGH_HIP(hipGetLastError());
+    return cgh_xsum_finalize(run, mode, d->hist, iter, d->tol, d->done, s);
+}
+
 extern "C" {
 
 // ------------------------------------------------------------------------------------------ communicator
@@ -955,6 +1002,15 @@ int cgh_dist_download_local(const cgh_dist *d, double *diag, double *ell_vals, i
 int cgh_dist_width(const cgh_dist *d) { return d->mat.K; }
 int64_t cgh_dist_halo(const cgh_dist *d) { return d->n_halo; }
 
+// Bit-identical mode for the solves started from now on (every rank makes the same choice): trajectory, x and the
+// converging iteration equal the reference's on the undistributed system, whatever the number of ranks.
+int cgh_dist_set_strict(cgh_dist *d, int strict)
+{
+    if (!d) return CGH_EINVAL;
+    d->strict = strict != 0;
+    return CGH_OK;
+}
+
 // ------------------------------------------------------------------------------------------ RCCL-driven loop
 int cgh_dist_start(cgh_dist *d, const double *d_b, double *d_x, double tol, int capacity)
 {
@@ -1000,6 +1056,13 @@ int cgh_dist_start(cgh_dist *d, const double *d_b, double *d_x, double tol, int 
     rc = spmv_ranges(d, true, true, false, &cnt, s, nullptr);  // Ap = A*0, as the reference computes it (cg.c:441)
     if (rc) return rc;
     hipLaunchKernelGGL(cg_init_rp, dim3(d->vgrid), dim3(CGH_BLOCK), 0, s, nl, d_b, (const double *)d->Ap, d->r, d->p, d->partB);
+    if (d->strict) {
+        d->xs = cgh_xsum_create(nl);
+        d->chain = (double *)cgh_alloc(sizeof(double) * 8);
+        if (!d->xs || !d->chain) return CGH_ENOMEM;
+        CGH_HIP(hipMemsetAsync(d->chain, 0, sizeof(double) * 8, s));
+        return strict_chain(d, d->r, d->r, d->r, 3, 0, 1, false, s);  // (rounds N .. 2N-1: iteration 1 goes on at 2N)
+    }
     if (g_rccl.p2p) {
         rc = cgh_p2p_launch(2, d->partB, d->vgrid, d->gs + 1, s);
         if (rc) return rc;
@@ -1078,6 +1141,21 @@ int cgh_dist_iterate(cgh_dist *d, int count, int time_kernels)
             if (rc) return rc;
         }
         if (time_kernels) CGH_HIP(hipEventRecord(d->kev.back(), s));
+        if (d->strict) {
+            // alpha, beta and the residual come from the chained order-exact sums; the vector kernels are the single-GPU
+            // strict ones (scalars from the history), the next halo leaves with the stand-alone push of the next iteration
+            rc = strict_chain(d, d->p, d->Ap, nullptr, 1, iter, 0, false, s);
+            if (rc) return rc;
+            hipLaunchKernelGGL((cg_update_r<1, 3>), dim3(d->vgrid), dim3(CGH_BLOCK), 0, s, nl, d->r, (const double *)d->Ap,
+                               (const double *)nullptr, 0, d->partB, d->hist, iter, (const int *)d->done, 0, (const double *)nullptr,
+                               cgh_xsum_cellsums(d->xs), cgh_xsum_cells(d->xs));
+            rc = strict_chain(d, d->r, d->r, d->r, 2, iter, 1, true, s);
+            if (rc) return rc;
+            hipLaunchKernelGGL((cg_update_xp<1, 3>), dim3(d->vgrid), dim3(CGH_BLOCK), 0, s, nl, d->x, (const double *)d->r, d->p,
+                               (const double *)nullptr, 0, d->hist, iter, d->tol, d->done, 0, (const double *)nullptr);
+            CGH_HIP(hipGetLastError());
+            continue;
+        }
         if (folded) {  // the all-reduces happen inside the kernels that consume them
             cgh_link L;
             rc = cgh_p2p_link(&L);

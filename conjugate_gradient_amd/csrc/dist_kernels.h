@@ -82,6 +82,32 @@ __global__ __launch_bounds__(CGH_BLOCK) void dist_update_r(int64_t n, double *__
     }
 }
 
+// One round of the chained order-exact sums (dist.hip, strict_chain): two doubles all-reduced over the ranks through the
+// mailboxes.  Exactly one rank contributes non-zero values, so the sum IS that rank's pair, bit for bit, on every rank.
+// The tag counts (solve, iteration, round) like every other exchange of the loop, and a frozen solve exchanges nothing
+// (the flag derives from the same totals on every rank), so ranks may queue different numbers of iterations after
+// convergence without losing step.
+// The mailbox slot of a round comes from a device-side count of the rounds actually EXECUTED (the same on every rank:
+// all ranks execute the same rounds), so two rounds that follow each other never share a slot -- also across the end of
+// a solve, where the round numbers jump.  (A rank may send round X+1 while a peer still reads round X, never more.)
+__global__ __launch_bounds__(CGH_BLOCK) void chain_round(cgh_link L, const double *__restrict__ mine, double *__restrict__ run,
+                                                        const int *__restrict__ done, int check_done, unsigned epoch, unsigned idx)
+{
+    __shared__ double ex[2 * CGH_LINK_MAX_RANKS];
+    if (check_done && *done != 0) return;
+    unsigned long long *executed = L.rounds;  // (one count per process: the solves of all objects share the mailbox)
+    const unsigned      seq = (unsigned)*executed;
+    L.region = 2;
+    L.tag = cgh_ll_tag(epoch, (idx << 2) | (seq & 3u));
+    double m[2] = {mine[0], mine[1]}, o[2];
+    link_allreduce<2>(L, m, o, ex);  // (its barriers separate the read of the count above from the store below)
+    if (threadIdx.x == 0) {
+        run[0] = o[0];
+        run[1] = o[1];
+        *executed = seq + 1ull;
+    }
+}
+
 __device__ __forceinline__ void push_row(const cgh_pushes &P, int64_t row, double v)
 {
     for (int j = 0; j < P.n; ++j) {

@@ -18,7 +18,7 @@
 
 constexpr int CGH_LINK_MAX_RANKS = 16, CGH_LINK_SLOTS = 4, CGH_LINK_WORDS = 4;
 // mailbox: [region][slot][sender rank][word]; region 0 = exchanges numbered by a host counter (p2p.hip: start-up, tests),
-// region 1 = exchanges numbered by iteration (this header)
+// region 1 = exchanges numbered by iteration (this header), region 2 = rounds of the chained order-exact sums
 constexpr size_t CGH_LINK_REGION_WORDS = (size_t)CGH_LINK_SLOTS * CGH_LINK_MAX_RANKS * CGH_LINK_WORDS;
 constexpr long long CGH_LL_TIMEOUT_TICKS = 1000000000ll;  // 10 s of the 100 MHz constant clock
 
@@ -29,6 +29,8 @@ struct cgh_link {
     int              nranks, me;
     int              self;   // 1: this rank's own value goes through its mailbox too (one-rank timing harness)
     unsigned         tag;    // of this exchange; its slot is (tag & 3)
+    unsigned         region; // of the mailbox: 1 = the two reductions of an iteration, 2 = rounds of the strict chain
+    unsigned long long *rounds;  // device: strict-chain rounds executed so far on this rank (the same on every rank)
 };
 
 struct cgh_ll_halo {
@@ -117,7 +119,7 @@ __device__ __forceinline__ void link_allreduce(const cgh_link &L, const double *
     const int t = threadIdx.x;
     if (L.nranks > 1 || L.self) {
         const int    slot = (int)(L.tag & (CGH_LINK_SLOTS - 1));
-        const size_t base = CGH_LINK_REGION_WORDS + (size_t)slot * CGH_LINK_MAX_RANKS * CGH_LINK_WORDS;
+        const size_t base = (size_t)L.region * CGH_LINK_REGION_WORDS + (size_t)slot * CGH_LINK_MAX_RANKS * CGH_LINK_WORDS;
         if (t < L.nranks * W) {
             const int peer = t / W, w = t % W;
             if (peer == L.me && !L.self) {

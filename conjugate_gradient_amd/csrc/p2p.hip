@@ -26,7 +26,7 @@ namespace {
 constexpr int P2P_MAX_RANKS = CGH_LINK_MAX_RANKS, P2P_SLOTS = CGH_LINK_SLOTS, P2P_WORDS = CGH_LINK_WORDS;
 // region 0: the exchanges of this file (numbered by g_p2p.seq); region 1: those folded into the kernels of the
 // iteration (halo_ll.h, numbered by solve and iteration)
-constexpr size_t P2P_BOX_WORDS = 2 * CGH_LINK_REGION_WORDS;
+constexpr size_t P2P_BOX_WORDS = 3 * CGH_LINK_REGION_WORDS;  // host-numbered | per iteration | rounds of the strict chain
 
 struct p2p_state {
     bool      connected = false;
@@ -35,6 +35,7 @@ struct p2p_state {
     void     *opened[P2P_MAX_RANKS] = {nullptr};   // hipIpcOpenMemHandle results (to close), NULL for self
     uint64_t **d_peers = nullptr;                  // device array [nranks]: every rank's mailbox as seen from here
     int       *d_err = nullptr;                    // device: 1 after a timed-out poll
+    unsigned long long *d_rounds = nullptr;        // device: rounds of the strict chain executed so far (dist_kernels.h, chain_round)
     unsigned   seq = 0;                            // exchanges so far (same on every rank)
 } g_p2p;
 
@@ -94,6 +95,8 @@ void p2p_release()
         }
     cgh_free(g_p2p.d_peers);
     cgh_free(g_p2p.d_err);
+    cgh_free(g_p2p.d_rounds);
+    g_p2p.d_rounds = nullptr;
     g_p2p.d_peers = nullptr;
     g_p2p.d_err = nullptr;
     g_p2p.connected = false;
@@ -159,7 +162,8 @@ int cgh_p2p_connect(int nranks, int rank, const char *handles)
     }
     g_p2p.d_peers = (uint64_t **)cgh_alloc(sizeof(uint64_t *) * P2P_MAX_RANKS);
     g_p2p.d_err = (int *)cgh_alloc(sizeof(int));
-    if (!g_p2p.d_peers || !g_p2p.d_err || cgh_h2d(g_p2p.d_peers, peers, sizeof peers) != CGH_OK ||
+    g_p2p.d_rounds = (unsigned long long *)cgh_alloc(sizeof(unsigned long long));
+    if (!g_p2p.d_peers || !g_p2p.d_err || !g_p2p.d_rounds || cgh_memset(g_p2p.d_rounds, 0, sizeof(unsigned long long)) != CGH_OK || cgh_h2d(g_p2p.d_peers, peers, sizeof peers) != CGH_OK ||
         cgh_memset(g_p2p.d_err, 0, sizeof(int)) != CGH_OK) {
         p2p_release();
         return CGH_ENOMEM;
@@ -220,6 +224,8 @@ int cgh_p2p_link(cgh_link *L)
     L->me = g_p2p.rank;
     L->self = 0;
     L->tag = 0;
+    L->region = 1;
+    L->rounds = g_p2p.d_rounds;
     return CGH_OK;
 }
 

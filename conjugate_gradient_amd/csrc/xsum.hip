@@ -360,7 +360,7 @@ __global__ __launch_bounds__(256) void xs_summarize(int64_t n, const double *__r
                                                    const double *__restrict__ c, int64_t ncells, int64_t ngroups,
                                                    const double *__restrict__ cellsum, const double *__restrict__ groupsum,
                                                    const double *__restrict__ gprefix, xs_summary *__restrict__ cells,
-                                                   xs_summary *__restrict__ groups)
+                                                   xs_summary *__restrict__ groups, const double *__restrict__ offsets)
 {
     constexpr int S0 = KIND == XS_L1 ? 1 : 0, S1 = KIND == XS_DOT ? 0 : 1;  // slots in use: S0..S1
     __shared__ double     start[2][XS_GROUP];  // predicted running sum at the start of each cell
@@ -380,6 +380,11 @@ __global__ __launch_bounds__(256) void xs_summarize(int64_t n, const double *__r
         before[slot] = gprefix    ? gprefix[slot * ngroups + g]
                        : groupsum ? block_sum_partials(groupsum + slot * ngroups, (int)g, 1, red)
                                   : block_sum_partials(cellsum + slot * ncells, (int)(g * XS_GROUP), 1, red);  // few cells
+    // a sum that continues another (the part of one rank of a distributed vector): what came before it, for the prediction
+    if (offsets != nullptr) {
+#pragma unroll
+        for (int slot = S0; slot <= S1; ++slot) before[slot] += offsets[slot];
+    }
     if (wave >= S0 && wave <= S1) {
         const int64_t cell = g * XS_GROUP + lane;
         const double  v = cell < ncells ? cellsum[wave * ncells + cell] : 0.0;
@@ -708,14 +713,14 @@ __device__ __forceinline__ double xd_chain(xd_shared &S, double s, int slot, int
 template <int KIND>
 __device__ double xd_sum(xd_shared &S, int slot, int64_t n, const double *__restrict__ a, const double *__restrict__ b,
                          const double *__restrict__ c, int64_t ncells, int64_t ngroups, const xs_summary *__restrict__ cells,
-                         const xs_summary *__restrict__ groups, long long *prof)
+                         const xs_summary *__restrict__ groups, double s0, long long *prof)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     cells += slot * ncells;
     if (groups) groups += slot * ngroups;
     const xs_summary *items = groups ? groups : cells;
     const int64_t     nitems = groups ? ngroups : ncells;
-    double            s = 0.0;
+    double            s = s0;
     const long long   tk0 = prof ? wall_clock64() : 0;
     int               ntrace = 0;
     for (int64_t base = 0; base < nitems; base += XD_ITEMS) {
@@ -821,44 +826,16 @@ __device__ double xd_sum(xd_shared &S, int slot, int64_t n, const double *__rest
     return s;
 }
 
-// Grid = one workgroup per sum in use (KIND 2: r.r and |r|_1 at once); the workgroup that finishes last finalises like
-// seq_sums (alpha / beta / residual / done flag).  xfer: [0..1] the sums, [2] tickets (zero between launches).
-template <int KIND>
-__global__ __launch_bounds__(XD_THREADS) void xs_drive(int64_t n, const double *__restrict__ a, const double *__restrict__ b,
-                                                      const double *__restrict__ c, int64_t ncells, int64_t ngroups,
-                                                      const xs_summary *__restrict__ cells, const xs_summary *__restrict__ groups,
-                                                      int mode, double *hist, int iter, double tol, int *done, double *out,
-                                                      double *xfer, long long *prof_buf)
+// What the sums are for (as seq_sums): mode 0 -> out[0..1]; 1 -> alpha of iteration `iter` from p.Ap; 2 -> residual, r.r,
+// beta, convergence flag; 3 -> the initial residual.
+__device__ __forceinline__ void xs_finalize(double s_dot, double s_l1, int mode, double *hist, int iter, double tol, int *done,
+                                            double *out)
 {
-    constexpr int S0 = KIND == XS_L1 ? 1 : 0, S1 = KIND == XS_DOT ? 0 : 1;
-    __shared__ xd_shared S;
-    const int  slot = S0 + (int)blockIdx.x;
-    const bool frozen = done != nullptr && mode != 3 && mode != 0 && *done != 0;
-    if (frozen) return;
-    long long      *prof = slot == S0 ? prof_buf : nullptr;
-    const long long t0 = prof ? wall_clock64() : 0;
-    const double    s = xd_sum<KIND>(S, slot, n, a, b, c, ncells, ngroups, cells, groups, prof);
-    if (threadIdx.x != 0) return;
-    if (prof) {
-        XS_PROF_ADD(3, wall_clock64() - t0 + (long long)(s != s));
-        XS_PROF_ADD(6, 1);
-    }
-    double s_dot = s, s_l1 = s;
-    if constexpr (S1 > S0) {
-        // two workgroups: the second to arrive has both sums (stores and loads at agent scope around the ticket)
-        unsigned long long *tk = reinterpret_cast<unsigned long long *>(xfer + 2);
-        __hip_atomic_store(xfer + slot, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned long long old = __hip_atomic_fetch_add(tk, 1ull, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-        if (old == 0) return;
-        __hip_atomic_store(tk, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_dot = __hip_atomic_load(xfer + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_l1 = __hip_atomic_load(xfer + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
     if (iter == 0 && mode == 1) iter = done[2] + 1;  // as seq_sums: iteration number from the device (graph replay)
     if (iter == 0 && mode == 2) iter = done[1];
     if (mode == 0) {
-        out[0] = KIND == XS_L1 ? 0.0 : s_dot;
-        out[1] = KIND == XS_DOT ? 0.0 : s_l1;
+        out[0] = s_dot;
+        out[1] = s_l1;
     } else if (mode == 1) {
         hist[(size_t)iter * CGH_HIST + 2] = hist[(size_t)(iter - 1) * CGH_HIST + 1] / s_dot;
     } else if (mode == 2) {
@@ -876,11 +853,63 @@ __global__ __launch_bounds__(XD_THREADS) void xs_drive(int64_t n, const double *
     }
 }
 
+// Grid = one workgroup per sum in use (KIND 2: r.r and |r|_1 at once); the workgroup that finishes last finalises like
+// seq_sums (alpha / beta / residual / done flag).  xfer: [0..1] the sums, [2] tickets (zero between launches).
+template <int KIND>
+__global__ __launch_bounds__(XD_THREADS) void xs_drive(int64_t n, const double *__restrict__ a, const double *__restrict__ b,
+                                                      const double *__restrict__ c, int64_t ncells, int64_t ngroups,
+                                                      const xs_summary *__restrict__ cells, const xs_summary *__restrict__ groups,
+                                                      int mode, double *hist, int iter, double tol, int *done, double *out,
+                                                      double *xfer, const double *s_in, double *s_out, long long *prof_buf)
+{
+    constexpr int S0 = KIND == XS_L1 ? 1 : 0, S1 = KIND == XS_DOT ? 0 : 1;
+    __shared__ xd_shared S;
+    const int  slot = S0 + (int)blockIdx.x;
+    // s_out: this is one rank's part of a longer sum -- start from s_in, leave the running sums, do not finalise
+    const bool frozen = done != nullptr && (s_out != nullptr || (mode != 3 && mode != 0)) && *done != 0;
+    if (frozen) {
+        if (s_out != nullptr && threadIdx.x == 0) s_out[slot] = 0.0;
+        return;
+    }
+    long long      *prof = slot == S0 ? prof_buf : nullptr;
+    const long long t0 = prof ? wall_clock64() : 0;
+    const double    s = xd_sum<KIND>(S, slot, n, a, b, c, ncells, ngroups, cells, groups, s_in ? s_in[slot] : 0.0, prof);
+    if (threadIdx.x != 0) return;
+    if (prof) {
+        XS_PROF_ADD(3, wall_clock64() - t0 + (long long)(s != s));
+        XS_PROF_ADD(6, 1);
+    }
+    if (s_out != nullptr) {
+        s_out[slot] = s;
+        if (S0 == S1) s_out[1 - slot] = s_in ? s_in[1 - slot] : 0.0;  // the sum not taken here passes through
+        return;
+    }
+    double s_dot = s, s_l1 = s;
+    if constexpr (S1 > S0) {
+        // two workgroups: the second to arrive has both sums (stores and loads at agent scope around the ticket)
+        unsigned long long *tk = reinterpret_cast<unsigned long long *>(xfer + 2);
+        __hip_atomic_store(xfer + slot, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long old = __hip_atomic_fetch_add(tk, 1ull, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (old == 0) return;
+        __hip_atomic_store(tk, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_dot = __hip_atomic_load(xfer + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_l1 = __hip_atomic_load(xfer + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    xs_finalize(KIND == XS_L1 ? 0.0 : s_dot, KIND == XS_DOT ? 0.0 : s_l1, mode, hist, iter, tol, done, out);
+}
+
+// The sums of a vector spread over several ranks, once the last rank's part is in (cgh_xsum_finalize): one thread.
+__global__ void xs_finalize_kernel(const double *__restrict__ sums, int mode, double *hist, int iter, double tol, int *done)
+{
+    const bool frozen = done != nullptr && mode != 3 && mode != 0 && *done != 0;
+    if (!frozen) xs_finalize(sums[0], sums[1], mode, hist, iter, tol, done, nullptr);
+}
+
 long long *g_xs_prof = nullptr;  // device buffer of 16 words, or NULL (cgh_xsum_set_prof)
 
 template <int KIND>
 int launch_all(cgh_xsum *w, bool presummed, int64_t n, const double *a, const double *b, const double *c, int mode, double *hist, int iter,
-               double tol, int *done, double *out, hipStream_t s)
+               double tol, int *done, double *out, hipStream_t s, const double *s_in = nullptr, double *s_out = nullptr)
 {
     const unsigned ng = (unsigned)w->ngroups;
     const double *gsum = w->groupsum;
@@ -905,15 +934,15 @@ int launch_all(cgh_xsum *w, bool presummed, int64_t n, const double *a, const do
     xs_summary *grp = flat ? nullptr : w->groups;
     if (flat)
         hipLaunchKernelGGL((xs_summarize<KIND, true>), dim3(4 * ng), dim3(256), 0, s, n, a, b, c, w->ncells, w->ngroups,
-                           (const double *)w->cellsum, gsum, prefix, w->cells, grp);
+                           (const double *)w->cellsum, gsum, prefix, w->cells, grp, s_in);
     else
         hipLaunchKernelGGL((xs_summarize<KIND, false>), dim3(ng), dim3(256), 0, s, n, a, b, c, w->ncells, w->ngroups,
-                           (const double *)w->cellsum, gsum, prefix, w->cells, grp);
+                           (const double *)w->cellsum, gsum, prefix, w->cells, grp, s_in);
     const int64_t nbatch = ((flat ? w->ncells : w->ngroups) + 63) / 64;
     const unsigned dthreads = nbatch >= XD_WAVES ? XD_THREADS : 64u * (unsigned)(nbatch < 1 ? 1 : nbatch);
     hipLaunchKernelGGL((xs_drive<KIND>), dim3(KIND == XS_BOTH_SAME ? 2 : 1), dim3(dthreads), 0, s, n, a, b, c, w->ncells,
                        w->ngroups, (const xs_summary *)w->cells, (const xs_summary *)grp, mode, hist, iter, tol, done, out, w->xfer,
-                       g_xs_prof);
+                       s_in, s_out, g_xs_prof);
     CGH_HIP(hipGetLastError());
     return CGH_OK;
 }
@@ -961,6 +990,27 @@ extern "C" void cgh_xsum_set_prof(void *dev_16_words) { g_xs_prof = (long long *
 
 double *cgh_xsum_cellsums(cgh_xsum *w) { return w ? w->cellsum : nullptr; }
 int64_t cgh_xsum_cells(const cgh_xsum *w) { return w ? w->ncells : 0; }
+
+// One rank's part of the sums of a vector spread over several ranks (rank order = element order): starts from the exact
+// running sums s_in[0..1] the ranks before left (device; NULL = this is the first part), leaves its own in s_out[0..1].
+// Nothing is finalised: cgh_xsum_finalize does that on every rank once the last part is in.
+int cgh_xsum_launch_part(cgh_xsum *w, int64_t n, const double *a, const double *b, const double *c, const double *s_in,
+                         double *s_out, const int *done, hipStream_t s, bool presummed)
+{
+    if (!w || n != w->n || !s_out) return CGH_EINVAL;
+    int *dn = const_cast<int *>(done);
+    if (a && b && !c) return launch_all<XS_DOT>(w, presummed, n, a, b, c, 1, nullptr, 0, 0.0, dn, nullptr, s, s_in, s_out);
+    if (!a && !b && c) return launch_all<XS_L1>(w, presummed, n, a, b, c, 1, nullptr, 0, 0.0, dn, nullptr, s, s_in, s_out);
+    if (a && a == b && a == c) return launch_all<XS_BOTH_SAME>(w, presummed, n, a, b, c, 1, nullptr, 0, 0.0, dn, nullptr, s, s_in, s_out);
+    return CGH_EINVAL;
+}
+
+int cgh_xsum_finalize(const double *sums, int mode, double *hist, int iter, double tol, int *done, hipStream_t s)
+{
+    hipLaunchKernelGGL(xs_finalize_kernel, dim3(1), dim3(1), 0, s, sums, mode, hist, iter, tol, done);
+    CGH_HIP(hipGetLastError());
+    return CGH_OK;
+}
 
 int cgh_xsum_launch(cgh_xsum *w, int64_t n, const double *a, const double *b, const double *c, int mode, double *hist,
                     int iter, double tol, int *done, double *out, hipStream_t s, bool presummed)

@@ -259,6 +259,12 @@ int64_t   cgh_dist_nnz_offdiag(const cgh_dist *d);
 /* The resumable CG loop on the rank's rows (same contract as cgh_solver_*; collective: every rank calls it
  * with the same counts).  transport: RCCL communicator from cgh_comm_init. */
 int cgh_dist_start(cgh_dist *d, const double *d_b_local, double *d_x_local, double tol, int iteration_capacity);
+/* Bit-identical mode of the distributed loop for the solves started afterwards (every rank makes the same choice): the two
+ * dots and the L1 norm become the reference's left-to-right sums over the GLOBAL vector (src/vec.c:67-85 there) --
+ * order-exact sums chained through the ranks in rank order -- so trajectory, x and the return value equal the reference's
+ * on the undistributed system bit for bit, whatever the number of ranks.  Serial in the number of ranks: a verification
+ * mode.  No reference counterpart (the reference is single-process). */
+int cgh_dist_set_strict(cgh_dist *d, int strict);
 int cgh_dist_iterate(cgh_dist *d, int count, int time_kernels);
 int cgh_dist_poll(cgh_dist *d, int *done_iter, int *queued);
 int cgh_dist_history(cgh_dist *d, int first, int count, double *h_out);

@@ -3,7 +3,7 @@ of the test box, so the transport is the peer-to-peer one throughout (mailbox al
 and descriptors travel through files.
     python dist_worker.py <rank> <nranks> <dir> <nx> <ny> <nz> <points> <max_iter> <tol>     z-slabs from the device generator
     python dist_worker.py <rank> <nranks> <dir> tag <golden input> 0 0 <max_iter> <tol>      row blocks of a stored system
-Writes hist_<rank>.npy and x_<rank>.npy.  A trailing "mute" makes rank 1 connect and then stay silent: rank 0's waits (halo
+Writes hist_<rank>.npy and x_<rank>.npy.  A trailing "strict" selects the bit-identical mode (cgh_dist_set_strict).  A trailing "mute" makes rank 1 connect and then stay silent: rank 0's waits (halo
 entries in the SpMV, reduction messages in the vector kernels) must end after their limit and surface as an error."""
 import ctypes as C
 import os
@@ -19,6 +19,7 @@ rank, nranks, d = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
 tag = sys.argv[5] if sys.argv[4] == "tag" else None
 nx, ny, nz, points = (0, 0, 0, 0) if tag else (int(v) for v in sys.argv[4:8])
 max_iter, tol = int(sys.argv[8]), float(sys.argv[9])
+strict = 1 if sys.argv[-1] == "strict" else 0
 
 
 def publish(name, data):
@@ -109,7 +110,7 @@ if sys.argv[-1] == "mute":                   # two ranks
     print("rank 0 ok timeout after %.1f s: %s" % (waited, failed), flush=True)
     sys.exit(0)
 
-D.start(b, x, tol, max_iter)
+D.start(b, x, tol, max_iter, strict)
 done, queued = 0, 0
 while queued < max_iter - 1 and not done:
     D.iterate(min(7, max_iter - 1 - queued), 0)
@@ -124,7 +125,7 @@ np.save(os.path.join(d, "x_%d.npy" % rank), x.to_host())
 # iterations (each stops at its own poll): the message tags count (solve, iteration), so the second solve must still
 # find every rank in step -- and give the same bits.
 x2 = cga.DeviceVector(nl)
-D.start(b, x2, tol, max_iter)
+D.start(b, x2, tol, max_iter, strict)
 done2, queued2 = 0, 0
 step = 5 + 3 * rank                        # ... and queue in different batch sizes this time
 while queued2 < max_iter - 1 and not done2:

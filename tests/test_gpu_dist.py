@@ -220,6 +220,43 @@ def test_multi_process_loop_from_partition(tmp_path, tag, G, env):
     _check_against_golden(hists[0].shape[0], hists[0], xs, g)
 
 
+@pytest.mark.parametrize("tag,G", [("cylinder_2000", 2), ("cylinder_8000", 4), ("cylinder_32k", 2), ("poisson7_16", 2),
+                                   ("poisson27_12x10x8", 4), ("poisson7_32x24x20", 8), ("cylinder_2000", 8),
+                                   ("poisson7_32x24x20", 3), ("cylinder_32k", 8)])
+def test_multi_process_strict_mode_is_bit_identical(tmp_path, tag, G):
+    """cgh_dist_set_strict: with 2, 3, 4 and 8 PROCESSES the whole trajectory (residual, r.r, alpha, beta of every
+    iteration), the converging iteration and the gathered x equal the reference's goldens of the UNdistributed system bit
+    for bit -- the OpenFOAM systems included, where the throughput-mode loop only agrees to rounding.  The order-exact
+    sums are chained through the ranks in rank order (dist.hip, strict_chain)."""
+    import os
+    import subprocess
+    import sys
+    g = golden(tag)
+    mi, tol = int(g["max_iter"]), float(g["tol"])
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "dist_worker.py")
+    procs = [subprocess.Popen([sys.executable, worker, str(r), str(G), str(tmp_path), "tag", tag, "0", "0", str(mi), str(tol), "strict"],
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(G)]
+    outs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=170)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append((p.returncode, out))
+    for r, (code, out) in enumerate(outs):
+        assert code == 0 and "rank %d ok" % r in out, out[-3000:]
+    hists = [np.load(os.path.join(tmp_path, "hist_%d.npy" % r)) for r in range(G)]
+    xs = np.concatenate([np.load(os.path.join(tmp_path, "x_%d.npy" % r)) for r in range(G)])
+    for h in hists[1:]:
+        assert same_bits_nan(h, hists[0])
+    want = g["traj"]
+    assert hists[0].shape[0] == want.shape[0], (hists[0].shape, want.shape)
+    assert same_bits_nan(hists[0], want)
+    assert np.array_equal(bits(xs), bits(g["cg_x"]))
+
+
 def test_multi_process_loop_silent_neighbour(tmp_path):
     """rank 1 connects and then says nothing: rank 0's waits inside the SpMV (halo entries) and inside the vector
     kernels (reduction messages) end after their 10 s limit, the results are NaN, cgh_dist_poll reports it, and work
