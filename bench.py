@@ -241,6 +241,10 @@ def main():
     powerlaw = wl[0] == "powerlaw"
     nx, ny, nz, points = (0, 0, 0, 0) if powerlaw else wl
     # CGH_BENCH_SHARE_GPU=1: every rank on device 0 (the rehearsal of the launcher protocol on a one-GPU box)
+    if os.environ.get("CGH_BENCH_SHARE_GPU") == "1":
+        # ranks that share a GPU must leave room for each other's waiting workgroups (dist.hip, alloc_solver_state),
+        # or the rehearsal stalls until the 10 s mailbox timeout
+        os.environ.setdefault("CGH_DIST_GRID_MAX", "64")
     cga.init(0 if os.environ.get("CGH_BENCH_SHARE_GPU") == "1" else local_rank)
 
     if world > 1 or args.dist:

@@ -20,24 +20,63 @@ import conjugate_gradient_amd as cga
 HBM_PEAK_GBS = 8000.0
 
 
+def launcher_start_time():
+    """wall-clock start of the launcher process (the parent of every rank): files of THIS run are younger than it"""
+    try:
+        with open("/proc/%d/stat" % os.getppid()) as f:
+            ticks = int(f.read().rsplit(")", 1)[1].split()[19])      # field 22: starttime, in clock ticks since boot
+        with open("/proc/stat") as f:
+            boot = next(int(line.split()[1]) for line in f if line.startswith("btime"))
+        return boot + ticks / os.sysconf("SC_CLK_TCK")
+    except (OSError, ValueError, StopIteration):
+        return 0.0
+
+
+def run_key():
+    """names the files of one launch: the launcher's pid AND start time (a recycled pid differs in the second), its
+    rendezvous port and, if the launcher is torchrun, its run id"""
+    rid = "".join(ch for ch in os.environ.get("TORCHELASTIC_RUN_ID", "") if ch.isalnum())[:16]
+    return "%d_%d_%s_%s" % (os.getppid(), int(launcher_start_time()), os.environ.get("MASTER_PORT", "0"), rid)
+
+
+def read_fresh(path, size):
+    """the file's bytes if it is complete and was written during this launch, else None (a leftover of a crashed run
+    with the same key would otherwise hand a dead id to ncclCommInitRank, which then hangs without a word)"""
+    try:
+        if os.stat(path).st_mtime + 1.0 < launcher_start_time():
+            return None
+        with open(path, "rb") as f:
+            data = f.read()
+        return data if len(data) == size else None
+    except FileNotFoundError:
+        return None
+
+
+def publish_exclusive(path, data):
+    """create-or-fail (O_EXCL) under a temporary name, then rename: nobody reads half a file, nobody follows a planted link"""
+    for stale in (path, path + ".tmp"):
+        try:
+            os.unlink(stale)
+        except FileNotFoundError:
+            pass
+    fd = os.open(path + ".tmp", os.O_WRONLY | os.O_CREAT | os.O_EXCL, 0o600)
+    with os.fdopen(fd, "wb") as f:
+        f.write(data)
+    os.replace(path + ".tmp", path)
+
+
 def exchange_unique_id(rank, world):
     """rank 0 creates the 256-byte id and publishes it atomically; the other ranks of the node wait for the file"""
-    path = "/tmp/cgh_uid_%d_%s" % (os.getppid(), os.environ.get("MASTER_PORT", "0"))
+    path = "/tmp/cgh_uid_%s" % run_key()
     if rank == 0:
         ident = cga.comm_unique_id()
-        with open(path + ".tmp", "wb") as f:
-            f.write(ident)
-        os.replace(path + ".tmp", path)
+        publish_exclusive(path, ident)
         return ident, path
     deadline = time.time() + 300.0
     while time.time() < deadline:
-        try:
-            with open(path, "rb") as f:
-                ident = f.read()
-            if len(ident) == 256:
-                return ident, path
-        except FileNotFoundError:
-            pass
+        ident = read_fresh(path, 256)
+        if ident is not None:
+            return ident, path
         time.sleep(0.02)
     raise SystemExit("bench_dist: rank %d never saw %s" % (rank, path))
 
@@ -48,25 +87,19 @@ def connect_without_rccl(rank, world):
     protocol is rehearsed with several ranks on ONE GPU (tests/test_gpu_bench_launcher.py), which RCCL refuses."""
     import ctypes as C
     L = cga.lib()
-    prefix = "/tmp/cgh_boot_%d_%s_" % (os.getppid(), os.environ.get("MASTER_PORT", "0"))
+    prefix = "/tmp/cgh_boot_%s_" % run_key()
 
     def publish(name, data):
-        with open(prefix + name + ".tmp", "wb") as f:
-            f.write(data)
-        os.replace(prefix + name + ".tmp", prefix + name)
+        publish_exclusive(prefix + name, data)
 
     def collect(name, size):
         out = []
         for r in range(world):
             deadline = time.time() + 300.0
             while True:
-                try:
-                    with open(prefix + name + str(r), "rb") as f:
-                        data = f.read()
-                    if len(data) == size:
-                        break
-                except FileNotFoundError:
-                    pass
+                data = read_fresh(prefix + name + str(r), size)
+                if data is not None:
+                    break
                 if time.time() > deadline:
                     raise SystemExit("bench_dist: rank %d never saw %s%s%d" % (rank, prefix, name, r))
                 time.sleep(0.02)
@@ -257,9 +290,13 @@ def run(args, rank, world, local_rank, shape, seed):
             out["config4"] = {"workload": "p27_512: 3-D 27-point Poisson 512^3, %d rows, %d off-diagonals, z-slabs over %d GPUs"
                                           % (extra["n"], extra["nnz_off"], world),
                               "value": extra["steps"] / extra["dt"], "unit": "iterations/s", "steps": extra["steps"],
-                              "ms_per_step": extra["ms_step"], "spmv_ms": extra["spmv_ms"],
-                              "spmv_GBs_algorithmic": extra["achieved"],
-                              "spmv_frac_of_peak": extra["achieved"] / (HBM_PEAK_GBS * world),
+                              "ms_per_step": extra["ms_step"],
+                              "roofline": {"bound": "hbm", "kernel": "spmv_ell_r2 (K=26, all local rows of the slowest rank, halo unpacked first; HIP events around every SpMV in a second pass)",
+                                           "achieved": extra["achieved"], "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
+                                           "frac": extra["achieved"] / (HBM_PEAK_GBS * world),
+                                           "bytes_per_launch": int(extra["alg_spmv"]), "ms_per_launch": extra["spmv_ms"],
+                                           "traffic": None},
+                              "iter_GBs_algorithmic": (12 * extra["nnz_off"] + 96 * extra["n"]) / (extra["ms_step"] * 1e-3) / 1e9,
                               "one_gpu_reference": "profiles/r01_bench_p27_512_n1.json (105 it/s on one MI355X)"}
         print(json.dumps(out), flush=True)
     barrier()
