@@ -154,7 +154,7 @@ void cgh_ell_dict_free(const cgh_matrix *m);
 
 // convert.hip
 cgh_matrix *cgh_matrix_from_entries_device(int64_t n, int64_t U, const double *d_diag, const double *d_upper,
-                                           const int *d_rows, const int *d_cols, int layout);
+                                           const int *d_rows, const int *d_cols, int layout, bool any_entries = false);
 
 // cg.hip: cgh_cg_solve with the history handed over window by window (dropin.hip prints from it)
 typedef void (*cgh_history_sink)(void *ctx, int first, int count, const double *entries, int converged_iteration,

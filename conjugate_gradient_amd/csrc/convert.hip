@@ -167,12 +167,13 @@ __global__ __launch_bounds__(256) void find_bad_entry(int64_t U, int64_t n, cons
 
 template <bool BOTH>
 __global__ __launch_bounds__(256) void count_placements(int64_t U, unsigned long long limit, const int *__restrict__ rows,
-                                                       const int *__restrict__ cols, int *__restrict__ cnt)
+                                                       const int *__restrict__ cols, int *__restrict__ cnt, int diag_twice)
 {
     for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < U; k += (int64_t)gridDim.x * 256) {
         const unsigned long long s0 = 2ull * k;
         if (s0 < limit) atomicAdd(&cnt[rows[k]], 1);
-        if (BOTH && s0 + 1 < limit && cols[k] != rows[k]) atomicAdd(&cnt[cols[k]], 1);  // a diagonal entry is placed once
+        // a diagonal entry is placed once -- unless the source's SpMV scatters whatever it is given (COO / CSR, diag_twice)
+        if (BOTH && s0 + 1 < limit && (cols[k] != rows[k] || diag_twice)) atomicAdd(&cnt[cols[k]], 1);
     }
 }
 
@@ -190,7 +191,7 @@ __global__ __launch_bounds__(256) void max_count(int64_t n, const int *__restric
 template <bool BOTH>
 __global__ __launch_bounds__(256) void bucket_placements(int64_t U, unsigned long long limit, const int *__restrict__ rows,
                                                         const int *__restrict__ cols, const int64_t *__restrict__ row_ptr,
-                                                        int *__restrict__ cursor, unsigned *__restrict__ seqs)
+                                                        int *__restrict__ cursor, unsigned *__restrict__ seqs, int diag_twice)
 {
     for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < U; k += (int64_t)gridDim.x * 256) {
         const unsigned long long s0 = 2ull * k;
@@ -198,7 +199,7 @@ __global__ __launch_bounds__(256) void bucket_placements(int64_t U, unsigned lon
             const int r = rows[k];
             seqs[row_ptr[r] + atomicAdd(&cursor[r], 1)] = (unsigned)s0;
         }
-        if (BOTH && s0 + 1 < limit && cols[k] != rows[k]) {
+        if (BOTH && s0 + 1 < limit && (cols[k] != rows[k] || diag_twice)) {
             const int r = cols[k];
             seqs[row_ptr[r] + atomicAdd(&cursor[r], 1)] = (unsigned)(s0 + 1);
         }
@@ -245,7 +246,7 @@ template <bool BOTH, typename ColT>
 __global__ __launch_bounds__(256) void place_entries(int64_t U, unsigned long long limit, const int *__restrict__ rows,
                                                     const int *__restrict__ cols, const double *__restrict__ vals,
                                                     const int64_t *__restrict__ row_ptr, const unsigned *__restrict__ seqs,
-                                                    out_desc o, unsigned long long *overflow_stop)
+                                                    out_desc o, unsigned long long *overflow_stop, int diag_twice = 0)
 {
     const int sides = BOTH ? 2 : 1;
     for (int64_t w = (int64_t)blockIdx.x * 256 + threadIdx.x; w < U * sides; w += (int64_t)gridDim.x * 256) {
@@ -253,7 +254,7 @@ __global__ __launch_bounds__(256) void place_entries(int64_t U, unsigned long lo
         const int                side = BOTH ? (int)(w & 1) : 0;
         const unsigned long long seq = 2ull * k + side;
         if (seq >= limit) continue;
-        if (side && cols[k] == rows[k]) continue;
+        if (side && cols[k] == rows[k] && !diag_twice) continue;
         const int     r = side ? cols[k] : rows[k];
         const int     c = side ? rows[k] : cols[k];
         const int64_t b0 = row_ptr[r], b1 = row_ptr[r + 1];
@@ -425,6 +426,7 @@ inline int grid_for(int64_t work) { return cgh_stream_grid((work + 255) / 256, 8
 struct cgh_buckets {
     int64_t            n = 0, U = 0;
     bool               both = true;
+    bool               diag_twice = false;  // an entry (i, i) is placed twice in row i (COO / CSR scatter semantics)
     unsigned long long limit = NO_STOP;  // placements with seq >= limit are not made
     unsigned long long bad_seq = NO_STOP;  // first bad entry (seq = 2k), NO_STOP if none
     int                max_count = 0;
@@ -451,6 +453,7 @@ int cgh_buckets_build(cgh_buckets *B, int64_t n, int64_t U, const int *d_rows, c
     B->n = n;
     B->U = U;
     B->both = both;
+    B->diag_twice = both && need_upper == 0;  // any (i, j): the symmetric scatter of the COO / CSR SpMVs, (i, i) included
     dev_buf stop(sizeof(unsigned long long)), mx(sizeof(int));
     B->cnt = (int *)cgh_alloc(sizeof(int) * (size_t)(n + 1));
     B->row_ptr = (int64_t *)cgh_alloc(sizeof(int64_t) * (size_t)(n + 2));
@@ -465,9 +468,9 @@ int cgh_buckets_build(cgh_buckets *B, int64_t n, int64_t U, const int *d_rows, c
     B->limit = B->bad_seq;
     if (U > 0) {
         if (both)
-            hipLaunchKernelGGL(count_placements<true>, dim3(g), dim3(256), 0, s, U, B->limit, d_rows, d_cols, B->cnt);
+            hipLaunchKernelGGL(count_placements<true>, dim3(g), dim3(256), 0, s, U, B->limit, d_rows, d_cols, B->cnt, B->diag_twice ? 1 : 0);
         else
-            hipLaunchKernelGGL(count_placements<false>, dim3(g), dim3(256), 0, s, U, B->limit, d_rows, d_cols, B->cnt);
+            hipLaunchKernelGGL(count_placements<false>, dim3(g), dim3(256), 0, s, U, B->limit, d_rows, d_cols, B->cnt, 0);
     }
     hipLaunchKernelGGL(max_count, dim3(grid_for(n)), dim3(256), 0, s, n, (const int *)B->cnt, mx.as<int>());
     int rc = cgh_exclusive_scan_i32_to_i64(B->cnt, B->row_ptr, n + 1, s);  // cnt[n] = 0 -> row_ptr[n] = total
@@ -482,10 +485,10 @@ int cgh_buckets_build(cgh_buckets *B, int64_t n, int64_t U, const int *d_rows, c
     if (U > 0) {
         if (both)
             hipLaunchKernelGGL(bucket_placements<true>, dim3(g), dim3(256), 0, s, U, B->limit, d_rows, d_cols,
-                               (const int64_t *)B->row_ptr, cursor.as<int>(), B->seqs);
+                               (const int64_t *)B->row_ptr, cursor.as<int>(), B->seqs, B->diag_twice ? 1 : 0);
         else
             hipLaunchKernelGGL(bucket_placements<false>, dim3(g), dim3(256), 0, s, U, B->limit, d_rows, d_cols,
-                               (const int64_t *)B->row_ptr, cursor.as<int>(), B->seqs);
+                               (const int64_t *)B->row_ptr, cursor.as<int>(), B->seqs, 0);
     }
     CGH_HIP(hipGetLastError());
     CGH_HIP(hipStreamSynchronize(s));  // cursor is freed on return
@@ -674,13 +677,15 @@ cgh_matrix *cgh_matrix_from_coo_device(int64_t n, int64_t U, const double *d_dia
 // d_diag == NULL: the entry list carries the diagonal itself as (i, i, a_ii) entries placed where the source
 // format's SpMV adds them (row-major upper ELL, reference ell.c:182-210, adds diag AFTER the contributions of
 // earlier rows); the matrix then gets an all-zero diag array, and 0.0 + 0.0*x = +0.0 starts each row's sum.
+// any_entries: the list is what the reference's COO / CSR SpMVs are given (coo.c:202-233, csr.c:190-229 there): entry k
+// adds v x[j] to y[i] and v x[i] to y[j] whatever (i, j) is -- lower entries and (i, i), which then counts twice, included.
 cgh_matrix *cgh_matrix_from_entries_device(int64_t n, int64_t U, const double *d_diag, const double *d_upper,
-                                           const int *d_rows, const int *d_cols, int layout)
+                                           const int *d_rows, const int *d_cols, int layout, bool any_entries)
 {
     CGH_REQUIRE_READY(nullptr);
     const bool inline_diag = d_diag == nullptr;
     if (layout == CGH_LAYOUT_CSRB) {
-        cgh_matrix *csr = cgh_matrix_from_entries_device(n, U, d_diag, d_upper, d_rows, d_cols, CGH_LAYOUT_CSR);
+        cgh_matrix *csr = cgh_matrix_from_entries_device(n, U, d_diag, d_upper, d_rows, d_cols, CGH_LAYOUT_CSR, any_entries);
         return csr ? cgh_csrb_from_csr(csr) : nullptr;
     }
     if (n <= 0 || U < 0 || (U > 0 && (!d_upper || !d_rows || !d_cols)) || layout < 0 || layout > CGH_LAYOUT_SELLS) {
@@ -689,10 +694,12 @@ cgh_matrix *cgh_matrix_from_entries_device(int64_t n, int64_t U, const double *d
     }
     hipStream_t s = g_cgh.stream;
     cgh_buckets B;
-    if (cgh_buckets_build(&B, n, U, d_rows, d_cols, true, inline_diag ? 2 : 1, s) != CGH_OK) return nullptr;
+    if (cgh_buckets_build(&B, n, U, d_rows, d_cols, true, any_entries ? 0 : (inline_diag ? 2 : 1), s) != CGH_OK) return nullptr;
     if (B.bad_seq != NO_STOP) {
-        cgh_set_error("cgh_matrix_from_coo: entry %llu is not strictly upper-triangular / in range (the reference's "
-                      "compute_max_nnz_row_full returns -1 here)", B.bad_seq >> 1);
+        cgh_set_error(any_entries ? "cgh_matrix_from_coo: entry %llu has an index outside [0, n)"
+                                  : "cgh_matrix_from_coo: entry %llu is not strictly upper-triangular / in range (the reference's "
+                                    "compute_max_nnz_row_full returns -1 here)",
+                      B.bad_seq >> 1);
         return nullptr;
     }
     cgh_matrix *m = new cgh_matrix();
@@ -801,7 +808,7 @@ cgh_matrix *cgh_matrix_from_entries_device(int64_t n, int64_t U, const double *d
         ok = ov.p != nullptr;
         if (ok && U > 0)
             hipLaunchKernelGGL((place_entries<true, int>), dim3(grid_for(2 * U)), dim3(256), 0, s, U, NO_STOP, d_rows, d_cols, d_upper,
-                               (const int64_t *)o.row_ptr, (const unsigned *)B.seqs, o, ov.as<unsigned long long>());
+                               (const int64_t *)o.row_ptr, (const unsigned *)B.seqs, o, ov.as<unsigned long long>(), B.diag_twice ? 1 : 0);
         ok = ok && hipGetLastError() == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
     }
     if (ok && layout == CGH_LAYOUT_CSR) ok = cgh_csr_build_row_blocks(m, s) == CGH_OK;

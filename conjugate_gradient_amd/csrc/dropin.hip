@@ -70,6 +70,17 @@ struct mat_guard {
     ~mat_guard() { cgh_matrix_free(m); }
 };
 
+// The entry list of the reference's COO SpMV / solver (host arrays): ANY (i, j) inside the matrix, as coo.c:202-233 there
+// serves them -- each entry scatters to y[i] and y[j], an (i, i) entry therefore twice.
+cgh_matrix *coo_any_from_host(int n, int count, const double *diag, const double *value, const int *rows, const int *cols, int layout)
+{
+    if (n <= 0 || count < 0 || !diag || (count > 0 && (!value || !rows || !cols))) return nullptr;
+    dbuf<double> dd(diag, (size_t)n), dv(value, (size_t)count);
+    dbuf<int>    dr(rows, (size_t)count), dc(cols, (size_t)count);
+    if (!dd.ok() || !dv.ok() || !dr.ok() || !dc.ok()) return nullptr;
+    return cgh_matrix_from_entries_device(n, count, dd.p, dv.p, dr.p, dc.p, layout, true);
+}
+
 // rows[] of a CSR-compressed upper triangle: rows[e] = r for row_ptr[r] <= e < row_ptr[r+1]
 __global__ __launch_bounds__(256) void expand_row_ptr(int64_t n, const int *__restrict__ row_ptr, int *__restrict__ rows)
 {
@@ -328,7 +339,7 @@ int conjugate_gradient_coo(const int n, double *diag, int coo_length, double *up
                            double *x, int max_iter, double tol)
 {
     if (!ensure_ready()) return -1;
-    mat_guard g{cgh_matrix_from_coo_host(n, coo_length, diag, upper, rows, cols, CGH_LAYOUT_ELL)};
+    mat_guard g{coo_any_from_host(n, coo_length, diag, upper, rows, cols, CGH_LAYOUT_ELL)};
     if (!g.m) return -1;
     return run_cg("CG (COO) \n\n", g.m, b, x, max_iter, tol);
 }
@@ -345,7 +356,7 @@ int conjugate_gradient_csr(const int n, double *diag, int upper_count, double *u
     dbuf<int>    drp(rows_ptr, (size_t)n + 1), dc(cols, (size_t)U), dr((size_t)U);
     if (!dd.ok() || !dv.ok() || !drp.ok() || !dc.ok() || !dr.ok()) return -1;
     hipLaunchKernelGGL(expand_row_ptr, dim3(grid_for(n)), dim3(256), 0, g_cgh.stream, (int64_t)n, (const int *)drp.p, dr.p);
-    mat_guard g{cgh_matrix_from_coo_device(n, U, dd.p, dv.p, dr.p, dc.p, CGH_LAYOUT_CSR)};
+    mat_guard g{cgh_matrix_from_entries_device(n, U, dd.p, dv.p, dr.p, dc.p, CGH_LAYOUT_CSR, true)};
     if (!g.m) return -1;
     g.m->exact_rows = true;  // the reference's order in every row, whatever its length
     return run_cg("CG (CSR) \n\n", g.m, b, x, max_iter, tol);
@@ -602,7 +613,7 @@ void mv_csr_symmetric(int n, const double *diag, const double *upper, const int 
     dbuf<int>    drp(row_ptr, (size_t)n + 1), dc(col_index, (size_t)U), dr((size_t)U);
     if (!dd.ok() || !dv.ok() || !drp.ok() || !dc.ok() || !dr.ok()) return;
     hipLaunchKernelGGL(expand_row_ptr, dim3(grid_for(n)), dim3(256), 0, g_cgh.stream, (int64_t)n, (const int *)drp.p, dr.p);
-    mat_guard g{cgh_matrix_from_coo_device(n, U, dd.p, dv.p, dr.p, dc.p, CGH_LAYOUT_CSR)};
+    mat_guard g{cgh_matrix_from_entries_device(n, U, dd.p, dv.p, dr.p, dc.p, CGH_LAYOUT_CSR, true)};
     if (!g.m) return;
     g.m->exact_rows = true;
     spmv_host(g.m, v, out);
@@ -614,7 +625,7 @@ void mv_coo_symmetric(int n, int coo_length, const double *diag, const double *v
                       const double *v, double *out)
 {
     if (!ensure_ready()) return;
-    mat_guard g{cgh_matrix_from_coo_host(n, coo_length, diag, value, rows, columns, CGH_LAYOUT_CSR)};
+    mat_guard g{coo_any_from_host(n, coo_length, diag, value, rows, columns, CGH_LAYOUT_CSR)};
     if (!g.m) return;
     g.m->exact_rows = true;
     spmv_host(g.m, v, out);

@@ -341,6 +341,44 @@ def test_tiny_and_odd_sizes(api, n):
         assert np.array_equal(bits(x), bits(ox)), (n, mi, tol)
 
 
+def test_coo_and_csr_take_any_entries_like_the_reference(api):
+    """The reference's COO and CSR SpMVs and solvers scatter whatever (i, j) they are given (coo.c:202-233, csr.c:190-229,
+    cg.c:21-222): lower-triangle entries, unsorted lists, duplicates, and (i, i) entries, which then count twice.  Same
+    bits here (the upper-triangle requirement belongs to the ELL converters only)."""
+    rng = np.random.default_rng(31)
+    n, cnt = 777, 5000
+    rows = rng.integers(0, n, cnt).astype(np.int32)
+    cols = rng.integers(0, n, cnt).astype(np.int32)
+    rows[:40] = cols[:40]                                   # entries on the diagonal
+    rows[40:60], cols[40:60] = rows[60:80], cols[60:80]     # duplicates
+    assert (rows > cols).any() and (rows < cols).any()
+    vals = -rng.random(cnt)
+    diag = np.full(n, 1.0)
+    np.add.at(diag, rows, -vals); np.add.at(diag, cols, -vals)   # dominant whatever the list holds
+    x = rng.standard_normal(n)
+    y = np.full(n, 7.0)
+    api.mv_coo_symmetric(n, cnt, D(diag), D(vals), I(rows), I(cols), D(x), D(y))
+    assert np.array_equal(bits(y), bits(O.mv_coo(n, diag, vals, rows, cols, x)))
+    # the same list as CSR rows (any column in any row)
+    order = np.argsort(rows, kind="stable")
+    r2, c2, v2 = rows[order], np.ascontiguousarray(cols[order]), np.ascontiguousarray(vals[order])
+    rp = np.zeros(n + 1, dtype=np.int32); np.add.at(rp, r2 + 1, 1); rp = np.cumsum(rp).astype(np.int32)
+    y[:] = 7.0
+    api.mv_csr_symmetric(n, D(diag), D(v2), I(c2), I(rp), D(x), D(y))
+    assert np.array_equal(bits(y), bits(O.mv_csr(n, diag, v2, c2, rp, x)))
+    b = rng.standard_normal(n)
+    ret, xs, oret, ox = _coo_solve(api, n, diag, vals, rows, cols, b)
+    assert ret == oret and ret > 0 and np.array_equal(bits(xs), bits(ox))
+    xs = np.full(n, 5.0)
+    ret = api.conjugate_gradient_csr(n, D(diag), cnt, D(v2), I(rp), I(c2), D(b), D(xs), 1000, 1e-6)
+    oret, ox, _ = O.cg(O.FMT_CSR, n, diag, cnt, v2, rp, c2, 0, b, 1000, 1e-6)
+    assert ret == oret and np.array_equal(bits(xs), bits(ox))
+    # an index outside the matrix stays an error (the reference would write out of bounds): -1, nothing solved
+    bad = cols.copy(); bad[7] = n
+    xs = np.full(n, 5.0)
+    assert api.conjugate_gradient_coo(n, D(diag), cnt, D(vals), I(rows), I(bad), D(b), D(xs), 1000, 1e-6) == -1
+
+
 def test_huge_max_iter_is_served_in_bounded_memory():
     """max_iter = INT_MAX ("until converged"): the reference's loop is O(1) in max_iter (src/cg.c:414-508) and so is the
     drop-in -- the history lives in a bounded window -- so the call returns the reference's 254 on foam-2000."""
