@@ -93,7 +93,8 @@ def cpu_baseline(A, b_dev, budget_s=15.0):
     t0 = time.perf_counter()
     spmv()
     t_spmv = time.perf_counter() - t0
-    iters = int(max(3, min(60, budget_s / (2.5 * t_spmv))))
+    # (small systems: up to 2000 iterations -- more would only time the arithmetic of a residual that has underflowed)
+    iters = int(max(3, min(60 if n > 4_000_000 else 2000, budget_s / (2.5 * t_spmv))))
     with quiet_stdout():
         t0 = time.perf_counter()
         solve(iters + 1)   # the loop runs iter = 1 .. max_iter-1; tol = -1 never converges
