@@ -95,7 +95,7 @@ def _free_port():
         return sk.getsockname()[1]
 
 
-def _gloo_worker(rank, world, port, tag, out):
+def _gloo_worker(rank, world, port, tag, out, strict=False):
     import torch
     import torch.distributed as dist
     sys.path.insert(0, HERE)
@@ -130,22 +130,45 @@ def _gloo_worker(rank, world, port, tag, out):
     def spmv(pext):
         return O.mv_ell_full(nl, P.K, P.diag, P.vals, P.cols, pext)
 
+    def chained(*term_vectors):
+        """the bit-identical mode of dist.hip (strict_chain): the reference's left-to-right sums over the GLOBAL vector --
+        round q: rank q continues the exact running sums over its own part, everybody else contributes zeros, one
+        all-reduce (s + 0 = s exactly) hands them on.  np.cumsum adds strictly in order."""
+        run = [0.0] * len(term_vectors)
+        for q in range(world):
+            mine = [float(np.cumsum(np.concatenate(([s0], t)))[-1]) if q == rank else 0.0 for s0, t in zip(run, term_vectors)]
+            run = allsum(*mine)
+        return run
+
+    if strict:
+        def sums_r(r):
+            return chained(r * r, np.abs(r))
+
+        def sum_pAp(p, Ap):
+            return chained(p * Ap)
+    else:
+        def sums_r(r):
+            return allsum(float(np.dot(r, r)), float(np.abs(r).sum()))
+
+        def sum_pAp(p, Ap):
+            return allsum(float(np.dot(p, Ap)))
+
     # the loop of dist.hip / reference cg.c:414-508
     x = np.zeros(nl)
     pext = np.zeros(nl + P.n_halo)
     r = b - spmv(pext)
     pext[:nl] = r
-    rr, l1 = allsum(float(np.dot(r, r)), float(np.abs(r).sum()))
+    rr, l1 = sums_r(r)
     traj = [l1 / 2.0]
     ret = -1
     for it in range(1, int(g["max_iter"])):
         halo_exchange(pext)
         Ap = spmv(pext)
-        (pAp,) = allsum(float(np.dot(pext[:nl], Ap)))
+        (pAp,) = sum_pAp(pext[:nl], Ap)
         alpha = rr / pAp
         x += alpha * pext[:nl]
         r -= alpha * Ap
-        rr_new, l1 = allsum(float(np.dot(r, r)), float(np.abs(r).sum()))
+        rr_new, l1 = sums_r(r)
         traj.append(l1 / 2.0)
         if l1 / 2.0 < float(g["tol"]):
             ret = it + 1
@@ -174,3 +197,18 @@ def test_two_rank_gloo_cg_matches_reference(tag, tmp_path):
     rel = np.abs(res["traj"][:m] - gt[:m]) / gt[:m]
     assert rel[:11].max() < 1e-10                                      # same bar as the single-GPU throughput mode
     assert np.abs(res["x"] - g["cg_x"]).max() <= 1e-5 * max(1.0, np.abs(g["cg_x"]).max())
+
+
+@pytest.mark.parametrize("tag,world", [("cylinder_2000", 2), ("poisson27_12x10x8", 3)])
+def test_gloo_strict_chain_is_bit_identical(tag, world, tmp_path):
+    """The bit-identical multi-GPU mode (cgh_dist_set_strict) restated on the CPU with gloo: sums chained through the ranks
+    in rank order give the reference's trajectory, return value and x bit for bit (the GPU version of this test:
+    tests/test_gpu_dist.py::test_multi_process_strict_mode_is_bit_identical)."""
+    import torch.multiprocessing as mp
+    port = _free_port()
+    out = str(tmp_path / "dist_strict.npz")
+    mp.spawn(_gloo_worker, args=(world, port, tag, out, True), nprocs=world, join=True)
+    res, g = np.load(out), _golden(tag)
+    assert int(res["ret"]) == int(g["cg_ret"][4])
+    assert np.array_equal(res["traj"].view(np.uint64), np.ascontiguousarray(g["traj"][:, 0]).view(np.uint64))
+    assert np.array_equal(res["x"].view(np.uint64), g["cg_x"].view(np.uint64))
