@@ -8,7 +8,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libcg_hip.so")
 
-LAYOUT_ELL, LAYOUT_CSR, LAYOUT_SELL, LAYOUT_CSRB, LAYOUT_SELLS = 0, 1, 2, 3, 4
+LAYOUT_ELL, LAYOUT_CSR, LAYOUT_SELL, LAYOUT_CSRB, LAYOUT_SELLS, LAYOUT_PB = 0, 1, 2, 3, 4, 5
 
 dp = C.POINTER(C.c_double)
 ip = C.POINTER(C.c_int)
@@ -66,6 +66,9 @@ def lib():
     L.cgh_config_sell_sigma.argtypes = [C.c_int]
     L.cgh_csrb_plan_host.argtypes = [i64, ip, C.c_int, ip, ip]
     L.cgh_csrb_plan_host.restype = i64
+    L.cgh_config_pb.argtypes = [C.c_int, i64, C.c_int]
+    L.cgh_pb_partition_host.argtypes = [i64, C.POINTER(C.c_int64), C.c_int, i64, C.POINTER(C.c_int64)]
+    L.cgh_pb_partition_host.restype = i64
     L.cgh_matrix_free.argtypes = [vp]
     L.cgh_matrix_free.restype = None
     for f in ("cgh_matrix_rows", "cgh_matrix_nnz_offdiag", "cgh_matrix_stored_bytes"):
@@ -166,6 +169,20 @@ def config_csrb(rows_per_wave_block=0, slab_bits=0, wgs_per_cu=0, window=-1, quo
 
 def config_sell_sigma(sigma):
     check(lib().cgh_config_sell_sigma(sigma), "cgh_config_sell_sigma")
+
+
+def config_pb(span_bits=0, target_entries=0, split=0):
+    """tuning of the two-phase (propagation-blocking) matrices constructed after the call (cgh_config_pb in include/cg_hip.h)"""
+    check(lib().cgh_config_pb(span_bits, target_entries, split), "cgh_config_pb")
+
+
+def pb_partition(cum, max_groups, target):
+    """host-side partition of the two-phase layout -> block boundaries in groups of 256 rows"""
+    c = np.ascontiguousarray(cum, dtype=np.int64)
+    out = np.zeros(c.size, dtype=np.int64)
+    B = lib().cgh_pb_partition_host(c.size - 1, c.ctypes.data_as(C.POINTER(C.c_int64)), max_groups, target,
+                                    out.ctypes.data_as(C.POINTER(C.c_int64)))
+    return out[:B + 1]
 
 
 def csrb_plan(weights, spb):

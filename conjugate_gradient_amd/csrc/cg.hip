@@ -214,9 +214,9 @@ int cgh_solver_start(cgh_solver *sv, const double *d_b, double *d_x, double tol,
         cgh_set_error("cgh_solver_start: d_b and d_x must be 16-byte aligned");
         return CGH_EINVAL;
     }
-    if (strict && sv->m->layout == CGH_LAYOUT_CSRB) {
-        cgh_set_error("cgh_solver_start: the column-blocked CSR sums a row slab by slab, not in the reference's order: it is a "
-                      "throughput layout (strict=0); for a bit-identical trajectory use CGH_LAYOUT_CSR with exact rows, ELL or sliced ELL");
+    if (strict && (sv->m->layout == CGH_LAYOUT_CSRB || sv->m->layout == CGH_LAYOUT_PB)) {
+        cgh_set_error("cgh_solver_start: the column-blocked layouts sum a row block by block, not in the reference's order: they are "
+                      "throughput layouts (strict=0); for a bit-identical trajectory use CGH_LAYOUT_CSR with exact rows, ELL or sliced ELL");
         return CGH_EINVAL;
     }
     hipStream_t   s = g_cgh.stream;

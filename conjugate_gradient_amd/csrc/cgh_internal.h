@@ -90,6 +90,16 @@ struct cgh_matrix {
     // perm[p] = row stored at position p (slice p/64, lane p%64), -1 beyond the last row
     int     *perm = nullptr;
     int      sigma = 0;
+    // PB (two-phase SpMV, spmv_pb.hip): rows = columns cut into pb_blocks blocks (pb_bnd, at most pb_span rows each); vals[] sorted
+    // by (row block, column block) with 2-byte local columns / rows; pb_prod is the launch's product stream (workspace of the
+    // matrix: launches on one matrix must not overlap)
+    int             pb_blocks = 0, pb_span = 0, pb_split = 1;
+    int            *pb_bnd = nullptr;   // [pb_blocks + 1] first row of each block
+    int            *pb_pre = nullptr;   // [pb_blocks][pb_blocks + 1] per column block: flat position of each of its segments
+    unsigned       *pb_seg0 = nullptr;  // [pb_blocks][pb_blocks] per column block: array position of each of its segments
+    int64_t        *pb_bin = nullptr;   // [pb_blocks + 1] array position of each row block
+    unsigned short *pb_lcol = nullptr, *pb_lrow = nullptr;  // [nnz_off]
+    double         *pb_prod = nullptr;  // [nnz_off]
 };
 
 // What a caller may ask of ONE SpMV launch beyond y = A x (explicit arguments: nothing about a launch travels through
@@ -121,6 +131,10 @@ struct cgh_config {
     int csrb_quorum_div = 2;    // CGH_CSRB_QUORUM: a gate opens once all but 1/div of the group's workgroups have passed
     int csrb_lds_atomics = 0;   // CGH_CSRB_LDS_ATOMICS: row sums by LDS atomics instead of segmented scan + read-add-write
     int sell_sigma = 65536;     // CGH_SELL_SIGMA: sorting window (rows) of the sigma-sorted sliced ELL
+    int pb_span_bits = 14;      // CGH_PB_SPAN_BITS: log2 of the most rows a block of the two-phase layout holds (13 | 14)
+    int64_t pb_target_entries = 131072; // CGH_PB_TARGET: entries per block the partition aims at
+    int pb_split = 1;           // CGH_PB_SPLIT: workgroups sharing one column block in phase 1
+    int pb_debug = 0;           // CGH_PB_DEBUG: experiment variants of pb_expand
 };
 extern cgh_config g_cfg;
 

@@ -614,14 +614,15 @@ int cgh_sort_coo_to_csr_device(int64_t n, int64_t nnz, const double *d_vals, con
 
 int cgh_csr_build_row_blocks(cgh_matrix *m, hipStream_t s);  // spmv_csr.hip
 cgh_matrix *cgh_csrb_from_csr(cgh_matrix *csr);                // spmv_csrb.hip
+cgh_matrix *cgh_pb_from_csr(cgh_matrix *csr);                  // spmv_pb.hip
 
 int cgh_csr_to_ell_download(const cgh_matrix *m, double *ell_vals, int *ell_cols)
 {
     const int64_t total = m->n * (int64_t)m->K;
     dev_buf       ev(sizeof(double) * (size_t)(total ? total : 1)), ec(sizeof(int) * (size_t)(total ? total : 1));
     if (!ev.p || !ec.p) return CGH_ENOMEM;
-    if (m->layout == CGH_LAYOUT_CSRB) {
-        cgh_set_error("cgh_matrix_download_ell: the column-blocked layout does not keep the rows' original entry order");
+    if (m->layout == CGH_LAYOUT_CSRB || m->layout == CGH_LAYOUT_PB) {
+        cgh_set_error("cgh_matrix_download_ell: the column-blocked layouts do not keep the rows' original entry order");
         return CGH_EINVAL;
     }
     dev_buf pos(sizeof(int) * (size_t)m->n);
@@ -687,6 +688,10 @@ cgh_matrix *cgh_matrix_from_entries_device(int64_t n, int64_t U, const double *d
     if (layout == CGH_LAYOUT_CSRB) {
         cgh_matrix *csr = cgh_matrix_from_entries_device(n, U, d_diag, d_upper, d_rows, d_cols, CGH_LAYOUT_CSR, any_entries);
         return csr ? cgh_csrb_from_csr(csr) : nullptr;
+    }
+    if (layout == CGH_LAYOUT_PB) {
+        cgh_matrix *csr = cgh_matrix_from_entries_device(n, U, d_diag, d_upper, d_rows, d_cols, CGH_LAYOUT_CSR, any_entries);
+        return csr ? cgh_pb_from_csr(csr) : nullptr;
     }
     if (n <= 0 || U < 0 || (U > 0 && (!d_upper || !d_rows || !d_cols)) || layout < 0 || layout > CGH_LAYOUT_SELLS) {
         cgh_set_error("cgh_matrix_from_coo: bad arguments (n=%lld U=%lld layout=%d)", (long long)n, (long long)U, layout);

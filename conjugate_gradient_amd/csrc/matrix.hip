@@ -11,6 +11,8 @@ int cgh_launch_spmv_sell(const cgh_matrix *m, const double *x, double *y, double
                          const int *done, hipStream_t s);
 int cgh_launch_spmv_csrb(const cgh_matrix *m, const double *x, double *y, double *dot_partials, int *grid_out,
                          const int *done, hipStream_t s);
+int cgh_launch_spmv_pb(const cgh_matrix *m, const double *x, double *y, double *dot_partials, int *grid_out,
+                       const int *done, hipStream_t s);
 int cgh_csr_to_ell_download(const cgh_matrix *m, double *ell_vals, int *ell_cols);
 
 int cgh_launch_spmv(const cgh_matrix *m, const double *x, double *y, double *dot_partials, int *grid_out,
@@ -23,6 +25,7 @@ int cgh_launch_spmv(const cgh_matrix *m, const double *x, double *y, double *dot
     case CGH_LAYOUT_SELL:
     case CGH_LAYOUT_SELLS: return cgh_launch_spmv_sell(m, x, y, dot_partials, grid_out, done, s);
     case CGH_LAYOUT_CSRB: return cgh_launch_spmv_csrb(m, x, y, dot_partials, grid_out, done, s);
+    case CGH_LAYOUT_PB: return cgh_launch_spmv_pb(m, x, y, dot_partials, grid_out, done, s);
     }
     cgh_set_error("cgh_spmv: unknown layout %d", m->layout);
     return CGH_EINVAL;
@@ -140,6 +143,13 @@ void cgh_matrix_free(cgh_matrix *m)
         cgh_free(m->tile_off);
         cgh_free(m->gate_prog);
         cgh_free(m->perm);
+        cgh_free(m->pb_bnd);
+        cgh_free(m->pb_pre);
+        cgh_free(m->pb_seg0);
+        cgh_free(m->pb_bin);
+        cgh_free(m->pb_lcol);
+        cgh_free(m->pb_lrow);
+        cgh_free(m->pb_prod);
     }
     cgh_ell_dict_free(m);
     delete m;
@@ -158,6 +168,7 @@ int64_t cgh_matrix_stored_bytes(const cgh_matrix *m)
     if (m->layout == CGH_LAYOUT_SELL) b += (m->nslices + 1) * 8;
     if (m->layout == CGH_LAYOUT_SELLS) b += (m->nslices + 1) * 8 + m->nslices * 64 * 4;
     if (m->layout == CGH_LAYOUT_CSRB) b += (m->nblocks + 1) * 8 + m->nblocks * (int64_t)(m->nslabs + 1) * 4 + m->nblocks * (m->rpw / 64) * 4;
+    if (m->layout == CGH_LAYOUT_PB) b += (int64_t)m->pb_blocks * (m->pb_blocks + 1) * 4 + (int64_t)m->pb_blocks * m->pb_blocks * 4 + (m->pb_blocks + 1) * 12;
     return b;
 }
 

@@ -40,6 +40,10 @@ static void read_env_knobs()
     g_cfg.csrb_quorum_div = env_int("CGH_CSRB_QUORUM", g_cfg.csrb_quorum_div);
     g_cfg.csrb_lds_atomics = env_int("CGH_CSRB_LDS_ATOMICS", g_cfg.csrb_lds_atomics);
     g_cfg.sell_sigma = env_int("CGH_SELL_SIGMA", g_cfg.sell_sigma);
+    g_cfg.pb_span_bits = env_int("CGH_PB_SPAN_BITS", g_cfg.pb_span_bits);
+    if (getenv("CGH_PB_TARGET")) g_cfg.pb_target_entries = atoll(getenv("CGH_PB_TARGET"));
+    g_cfg.pb_split = env_int("CGH_PB_SPLIT", g_cfg.pb_split);
+    g_cfg.pb_debug = env_int("CGH_PB_DEBUG", g_cfg.pb_debug);
 }
 
 extern "C" {

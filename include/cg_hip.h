@@ -67,8 +67,12 @@ enum {
                              rows dealt in 64-row segments to wave-blocks of equal weight, a block's entries sorted by
                              column slab so that every wave on the chip gathers from the same ~1 MiB window of x at the
                              same time; per-row sums in a fixed order (deterministic) that is NOT the reference's order */
-    CGH_LAYOUT_SELLS = 4  /* sigma-sorted sliced ELL (SELL-C-sigma, C = 64): rows sorted by length inside windows of
+    CGH_LAYOUT_SELLS = 4, /* sigma-sorted sliced ELL (SELL-C-sigma, C = 64): rows sorted by length inside windows of
                              sigma rows before slicing, the permutation folded into y; per-row order = the reference's */
+    CGH_LAYOUT_PB = 5     /* two-phase SpMV (propagation blocking; throughput layout for scattered columns, BASELINE config 5):
+                             entries sorted by (row block, column block) with 2-byte local indices; phase 1 multiplies by x
+                             staged in LDS and streams the products, phase 2 adds them into row sums held in LDS -- no random
+                             access leaves the CU; a row's sum is added in no fixed order (agrees to rounding, not bit for bit) */
 };
 
 /* Host slot-major full ELL (what coo_to_ell_symmetric_full_colmajor produced) -> device. */
@@ -104,6 +108,13 @@ int     cgh_matrix_set_exact_rows(cgh_matrix *m, int exact);
  * Sorting window (rows) of the sigma-sorted sliced ELL. */
 int     cgh_config_csrb(int rows_per_wave_block, int slab_bits, int wgs_per_cu, int window, int quorum_div, int lds_atomics);
 int     cgh_config_sell_sigma(int sigma_rows);
+/* Tuning of the CGH_LAYOUT_PB matrices constructed after the call (0 keeps): log2 of the most rows per block (13 | 14), entries
+ * per block the partition aims at, workgroups sharing one column block in phase 1 (1..16). */
+int     cgh_config_pb(int span_bits, int64_t target_entries, int split);
+/* Host-side partition of the two-phase layout (no GPU needed; exported for tests): cuts G groups of 256 rows (cum[g] =
+ * entries before group g, cum[G] = all) into consecutive blocks of at most max_groups groups and, where that leaves a
+ * choice, at most `target` entries.  bnd_g[0..B] receives the boundaries in groups.  Returns B. */
+int64_t cgh_pb_partition_host(int64_t G, const int64_t *cum, int max_groups, int64_t target, int64_t *bnd_g);
 /* The CGH_* environment knobs (DESIGN.md lists them) are read ONCE, by cgh_init, never in a launch path; a host that
  * changes the environment afterwards (tests do) calls this to have them read again. */
 int     cgh_config_reload(void);
