@@ -260,7 +260,7 @@ def main():
     b = cga.DeviceVector(n)
     x = cga.DeviceVector(n)
     if powerlaw:
-        A = cga.Matrix.powerlaw(n, wl[2], PL_SEED, cga.LAYOUT_CSRB, b)
+        A = cga.Matrix.powerlaw(n, wl[2], PL_SEED, cga.LAYOUT_PB, b)
     else:
         A = cga.Matrix.poisson(nx, ny, nz, points, SEED, cga.LAYOUT_ELL, b)
     sv = cga.Solver(A, args.warmup + args.steps + 1)
@@ -280,9 +280,10 @@ def main():
     ms_step = dt / args.steps * 1e3
     if powerlaw:
         what = ("%s: SPD matrix with power-law row lengths (Pareto exponent 2, 1..%d entries per row, realised max %d, mean %.2f), "
-                "columns uniformly random, %d rows, column-blocked CSR, unpreconditioned CG" % (args.workload, wl[2], A.K, A.nnz_offdiag / n, n))
-        kernel = ("spmv_csrb (column-blocked CSR SpMV + p.Ap partials: 12 bytes per entry, row sums in LDS, gathers of x paced "
-                  "slab by slab through L2; HIP events around every 4th launch of the timed region)")
+                "columns uniformly random, %d rows, two-phase (propagation-blocking) layout, unpreconditioned CG" % (args.workload, wl[2], A.K, A.nnz_offdiag / n, n))
+        kernel = ("pb_expand + pb_accumulate (two-phase SpMV + p.Ap partials: 12 bytes per stored entry; phase 1 multiplies by x staged in "
+                  "LDS and streams the products through HBM, phase 2 adds them into row sums held in LDS; achieved = algorithmic bytes / "
+                  "time of BOTH launches; HIP events around every 4th SpMV of the timed region)")
     else:
         what = "%s: 3-D %d-point Poisson %dx%dx%d, %d rows, slot-major ELL K=%d, unpreconditioned CG" % (args.workload, points, nx, ny, nz, n, A.K)
         kernel = "spmv_ell_r2 (SpMV + p.Ap partials; %s; HIP events around every 4th launch of the timed region)" % (
@@ -348,7 +349,8 @@ def main():
         y = cga.DeviceVector(n)
         lay = {}
         csr_bytes = None
-        for name, layout in (("csr_stream_adaptive", cga.LAYOUT_CSR), ("sliced_ell_sigma_sorted", cga.LAYOUT_SELLS), ("sliced_ell_64", cga.LAYOUT_SELL)):
+        for name, layout in (("csr_stream_adaptive", cga.LAYOUT_CSR), ("column_blocked_csr", cga.LAYOUT_CSRB),
+                             ("sliced_ell_sigma_sorted", cga.LAYOUT_SELLS), ("sliced_ell_64", cga.LAYOUT_SELL)):
             M = cga.Matrix.powerlaw(n, wl[2], PL_SEED, layout, b)
             cga.check(cga.lib().cgh_time_spmv(M.h, b.ptr, y.ptr, 10, C.byref(ms)))
             if layout == cga.LAYOUT_CSR:
@@ -358,8 +360,10 @@ def main():
             if layout == cga.LAYOUT_CSR and not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline_csr(M, b)
             M.free()
-        lay["column_blocked_csr"] = {"spmv_ms": spmv_ms, "spmv_GBs_algorithmic": achieved, "frac": achieved / HBM_PEAK_GBS,
-                                     "note": "the headline kernel; 12 bytes per entry + slab offsets, parity by tolerance (fixed order, not the reference's)"}
+        lay["column_blocked_csr"]["note"] = "round 2's first throughput layout: gathers of x paced slab by slab through L2; fixed order, not the reference's"
+        lay["two_phase"] = {"spmv_ms": spmv_ms, "spmv_GBs_algorithmic": achieved, "frac": achieved / HBM_PEAK_GBS,
+                            "note": "the headline kernels; 12 bytes per stored entry (+ 3 % padding) and a product stream of 8 bytes per entry "
+                                    "written and read back; parity by tolerance (row sums by LDS atomics: no fixed order)"}
         out["config"]["layouts"] = lay
         lay["ell_single_width"] = {"stored_bytes": int(n * Kfull * 12 + n * 8), "bytes_vs_csr": (n * Kfull * 12 + n * 8) / csr_bytes,
                                    "note": "not instantiated: what the reference's one-width ELL (src/ell.c:791-858) would store at K = %d" % Kfull}

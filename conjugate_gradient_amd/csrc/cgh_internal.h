@@ -134,7 +134,6 @@ struct cgh_config {
     int pb_span_bits = 14;      // CGH_PB_SPAN_BITS: log2 of the most rows a block of the two-phase layout holds (13 | 14)
     int64_t pb_target_entries = 131072; // CGH_PB_TARGET: entries per block the partition aims at
     int pb_split = 1;           // CGH_PB_SPLIT: workgroups sharing one column block in phase 1
-    int pb_debug = 0;           // CGH_PB_DEBUG: experiment variants of pb_expand
 };
 extern cgh_config g_cfg;
 

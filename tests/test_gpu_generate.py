@@ -100,7 +100,8 @@ def test_config5_full_size_properties(cga):
     (2) A*1 = 1 up to the rounding of one row (diag = 1 + sum|a_ij|, a_ij <= 0);
     (3) symmetry: z.(A x) = x.(A z) to rounding;
     (4) the column-blocked CSR (throughput layout, fixed order that is not the reference's) agrees with (1) to a few
-        ulps of sum|a_ij x_j| per row, and gives the same bits on every run."""
+        ulps of sum|a_ij x_j| per row, and gives the same bits on every run;
+    (5) the two-phase layout (throughput layout, LDS atomics: no fixed order) agrees with (1) to the same bound, run after run."""
     n, max_len, seed = 8 * 1024 * 1024, 2000, 0x5EED0005
     rng = np.random.default_rng(5)
     xh, zh = rng.standard_normal(n), rng.standard_normal(n)
@@ -108,7 +109,8 @@ def test_config5_full_size_properties(cga):
     ys, stored = {}, {}
     cga.config_sell_sigma(65536)
     cga.config_csrb(1024, 17, 0, 3, 2, 0)
-    for layout in (cga.LAYOUT_CSR, cga.LAYOUT_SELL, cga.LAYOUT_SELLS, cga.LAYOUT_CSRB):
+    cga.config_pb(14, 131072, 1)
+    for layout in (cga.LAYOUT_CSR, cga.LAYOUT_SELL, cga.LAYOUT_SELLS, cga.LAYOUT_CSRB, cga.LAYOUT_PB):
         b = cga.DeviceVector(n)
         A = cga.Matrix.powerlaw(n, max_len, seed, layout, b)
         A.set_exact_rows(True)
@@ -130,6 +132,10 @@ def test_config5_full_size_properties(cga):
         if layout == cga.LAYOUT_CSRB:
             A.spmv(x, y)
             assert np.array_equal(bits(y.to_host()), bits(yx))              # (4) deterministic
+        if layout == cga.LAYOUT_PB:
+            A.spmv(x, y)
+            err = np.abs(y.to_host() - ys[cga.LAYOUT_CSR][0])                # (5) again, second run
+            assert np.all(err <= 64 * np.finfo(float).eps * bound), float((err / bound).max())
         ys[layout] = (yx, y1)
         A.free()
     for lay in (cga.LAYOUT_SELL, cga.LAYOUT_SELLS):                         # (1)
@@ -140,3 +146,7 @@ def test_config5_full_size_properties(cga):
     err = np.abs(ys[cga.LAYOUT_CSRB][0] - ys[cga.LAYOUT_CSR][0])            # (4)
     assert np.all(err <= 64 * np.finfo(float).eps * bound), float((err / bound).max())
     assert np.max(np.abs(ys[cga.LAYOUT_CSRB][1] - 1.0) / diag) < 1e-12
+    assert stored[cga.LAYOUT_PB] < 1.05 * stored[cga.LAYOUT_CSR]
+    err = np.abs(ys[cga.LAYOUT_PB][0] - ys[cga.LAYOUT_CSR][0])              # (5)
+    assert np.all(err <= 64 * np.finfo(float).eps * bound), float((err / bound).max())
+    assert np.max(np.abs(ys[cga.LAYOUT_PB][1] - 1.0) / diag) < 1e-12

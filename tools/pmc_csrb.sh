@@ -12,4 +12,4 @@ for pass in "FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum" "SQ_WAVE_CYCLES S
   (cd $R && timeout -s KILL 120 rocprofv3 --pmc $pass --output-format csv -d $d -- python3 tools/prof_csrb.py $L "$@") > $d.log 2>&1 || { echo "pass $pass failed"; tail -5 $d.log; exit 1; }
 done
 (cd $R && timeout -s KILL 120 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/L${L}_trace -- python3 tools/prof_csrb.py $L "$@") > $OUT/L${L}_trace.log 2>&1
-cd $R && python3 tools/pmc_summary.py $OUT/L${L}_* | grep -i "spmv\|copy" 
+cd $R && python3 tools/pmc_summary.py $OUT/L${L}_* | grep -i "spmv\|copy\|pb_\|read8"
