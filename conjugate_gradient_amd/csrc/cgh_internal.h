@@ -120,6 +120,7 @@ struct cgh_config {
     int    csr_window = 1024;   // CGH_CSR_WINDOW: entries per row block of the CSR stream kernel (512 | 1024 | 2048)
     int    csr_exact = 0;       // CGH_CSR_EXACT: every CSR row summed strictly left to right
     int64_t xsum_min_rows = 4096; // CGH_XSUM_MIN_ROWS: shortest vector taking the order-exact parallel sums (-1 never)
+    int    xsum_fused = 1;      // CGH_XSUM_FUSED: summaries and walk of the order-exact sums in one launch (0: two launches)
     int    serpentine = 0;      // CGH_SERPENTINE: alternate the sweep direction of the iteration's kernels
     int    vec_variant = -1;    // CGH_VEC_VARIANT: cache-hint variant of the vector kernels, -1 = by working-set size
     int    graph = 0;           // CGH_GRAPH: replay batches of iterations from HIP graphs

@@ -2,7 +2,8 @@
 // (src/vec.c:67-85 there) reproduced bit for bit at streaming speed.  Arithmetic and proof sketch: xsum.h;
 // host model of the same algorithm: oracle/xsum_model.cpp (tests/test_xsum_model.py).
 //
-// Four launches per call, for one or two sums over the same index range (slot 0 = dot, slot 1 = l1):
+// Launches per call, for one or two sums over the same index range (slot 0 = dot, slot 1 = l1); from 2049 cells on,
+// xs_summarize and xs_drive run as ONE launch, xs_fused (further down), whose driver walks while the summaries are built:
 //   xs_cell_sums   one workgroup per group (64 cells x 128 elements): approximate (tree) sum of every cell and group
 //   xs_group_scan  one workgroup: exclusive prefix of the group sums (only beyond 4096 groups; below that every
 //                  workgroup of xs_summarize adds up the sums of the groups before it)
@@ -25,6 +26,8 @@ struct cgh_xsum {
     xs_summary *cells = nullptr;     // [2][ncells]
     xs_summary *groups = nullptr;    // [2][ngroups]
     double     *xfer = nullptr;      // [4]: the two sums on their way to the finalising workgroup, its ticket
+    unsigned   *ready = nullptr;     // [2][batches of 64 groups]: groups summarised so far in the running fused launch (zero between launches)
+    xs_summary *batches = nullptr;   // [2][batches]: the join of each batch's group summaries (fused launch)
 };
 
 namespace {
@@ -347,6 +350,43 @@ __device__ __forceinline__ void xs_terms8(int64_t n, const double *__restrict__ 
     }
 }
 
+// Summaries that a workgroup on another XCD reads in the SAME launch (the fused kernel, below): agent-scope stores write
+// through the XCD's L2, agent-scope loads do not trust it; no fence (an agent-scope release per workgroup writes back the
+// whole L2 and doubled the kernel's time).
+__device__ __forceinline__ void xs_store_words_agent(unsigned long long *dst, const unsigned long long *src, int words)
+{
+    for (int i = threadIdx.x; i < words; i += blockDim.x) __hip_atomic_store(dst + i, src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ xs_summary xs_load_agent(const xs_summary *src)
+{
+    const unsigned long long *d = reinterpret_cast<const unsigned long long *>(src);
+    xs_summary                q;
+    q.A = (int64_t)__hip_atomic_load(d + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    q.C = (int64_t)__hip_atomic_load(d + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    q.Mlo = (int64_t)__hip_atomic_load(d + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    q.Mhi = (int64_t)__hip_atomic_load(d + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long em = __hip_atomic_load(d + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    q.E = (int32_t)(uint32_t)em;
+    q.meta = (int32_t)(uint32_t)(em >> 32);
+    return q;
+}
+static_assert(sizeof(xs_summary) == 40, "xs_summary is read and written as five 64-bit words");
+constexpr unsigned XS_BATCH_READY = 1u << 16;  // added to a batch's count of summarised groups once its own summary is in memory
+// word `k` (0..4, one per lane) of lane 0's summary
+__device__ __forceinline__ unsigned long long readlane_words(const xs_summary &q, int k)
+{
+    const unsigned long long w[5] = {(unsigned long long)q.A, (unsigned long long)q.C, (unsigned long long)q.Mlo, (unsigned long long)q.Mhi,
+                                     (unsigned long long)(uint32_t)q.E | ((unsigned long long)(uint32_t)q.meta << 32)};
+    unsigned long long       r = 0;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(uint32_t)w[i]);
+        const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(uint32_t)(w[i] >> 32));
+        if (k == i) r = ((unsigned long long)hi << 32) | lo;
+    }
+    return r;
+}
+
 __device__ __noinline__ xs_summary xs_cell16_exact(const double *t, int32_t E, int32_t neg, int64_t Mt)
 {
     return xs_cell16_exact_impl<1>(t, E, neg, Mt);
@@ -355,24 +395,36 @@ __device__ __noinline__ xs_summary xs_cell16_exact(const double *t, int32_t E, i
 // One workgroup per group.  16 lanes share a cell (8 consecutive elements each: a short serial prefix in registers,
 // then a 4-step tree inside the 16 lanes), so a wave summarises 4 cells at a time and the workgroup 16.  Inside a
 // cell no saturation is needed: 128 elements of |d| < 2^52 stay below 2^59.
-template <int KIND, bool FLAT>
-__global__ __launch_bounds__(256) void xs_summarize(int64_t n, const double *__restrict__ a, const double *__restrict__ b,
-                                                   const double *__restrict__ c, int64_t ncells, int64_t ngroups,
-                                                   const double *__restrict__ cellsum, const double *__restrict__ groupsum,
-                                                   const double *__restrict__ gprefix, xs_summary *__restrict__ cells,
-                                                   xs_summary *__restrict__ groups, const double *__restrict__ offsets)
+template <int NS>
+struct xsm_shared {
+    double     start[2][XS_GROUP];  // predicted running sum at the start of each cell
+    xs_summary sm[2][XS_GROUP];
+    double     red[4];
+    __attribute__((aligned(16))) double tr[NS][4][64 * 10];  // per slot: 4 waves x 64 rows of 8 terms (+2 of padding)
+};
+
+// `bid` = the workgroup's number among those that summarise.  FUSED: the driver runs in the same launch (xs_fused): the
+// summaries are written through to memory and the group is counted in ready[slot][batch of the group].
+template <int KIND, bool FLAT, bool FUSED>
+__device__ __forceinline__ void xs_summarize_body(xsm_shared<(KIND == XS_BOTH_SAME ? 2 : 1)> &W, const unsigned bid, int64_t n,
+                                                  const double *__restrict__ a, const double *__restrict__ b,
+                                                  const double *__restrict__ c, int64_t ncells, int64_t ngroups,
+                                                  const double *__restrict__ cellsum, const double *__restrict__ groupsum,
+                                                  const double *__restrict__ gprefix, xs_summary *__restrict__ cells,
+                                                  xs_summary *__restrict__ groups, const double *__restrict__ offsets,
+                                                  unsigned *__restrict__ ready, xs_summary *__restrict__ batches, int64_t nbatch)
 {
     constexpr int S0 = KIND == XS_L1 ? 1 : 0, S1 = KIND == XS_DOT ? 0 : 1;  // slots in use: S0..S1
-    __shared__ double     start[2][XS_GROUP];  // predicted running sum at the start of each cell
-    __shared__ xs_summary sm[2][XS_GROUP];
-    __shared__ double     red[4];
-    constexpr int XS_TR = 4 * 64 * 10;  // doubles per slot: 4 waves x 64 rows of 8 terms (+2 of padding)
-    __shared__ __attribute__((aligned(16))) double tr[S1 - S0 + 1][4][64 * 10];
+    auto &start = W.start;
+    auto &sm = W.sm;
+    auto &red = W.red;
+    auto &tr = W.tr;
+    constexpr int XS_TR = 4 * 64 * 10;  // doubles per slot
     const int     lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // groups == NULL ("flat", few cells): four workgroups per group, one pass of 16 cells each, no group summary --
     // the whole problem is then a handful of workgroups, and their serial depth is what counts
     constexpr bool flat = FLAT;  // (groups == NULL)
-    const int64_t g = flat ? blockIdx.x >> 2 : blockIdx.x;
+    const int64_t g = flat ? bid >> 2 : bid;
     // approximate sum of everything before this group: from the scan kernel, or (few groups) summed here
     double before[2] = {0.0, 0.0};
 #pragma unroll
@@ -398,7 +450,7 @@ __global__ __launch_bounds__(256) void xs_summarize(int64_t n, const double *__r
     }
     __syncthreads();
     const int sub = threadIdx.x & 15;  // position inside the cell's 16 lanes
-    const int pass_lo = flat ? (int)(blockIdx.x & 3) : 0, pass_hi = flat ? pass_lo + 1 : 4;
+    const int pass_lo = flat ? (int)(bid & 3) : 0, pass_hi = flat ? pass_lo + 1 : 4;
     // Loads are coalesced -- load j of a lane fetches elements 32 j + 2 sub, + 1 of its cell, so 16 lanes read 256
     // contiguous bytes (8 consecutive elements per lane, the layout the scan wants, made every load touch 64 different
     // lines: 3.8 TB/s at best) -- and the terms go through LDS to reach the lane that scans them: lane r of the cell owns
@@ -501,17 +553,76 @@ __global__ __launch_bounds__(256) void xs_summarize(int64_t n, const double *__r
                 if (want) q = ex;
             }
             if (sub == 0) {
-                if (cell < ncells) cells[slot * ncells + cell] = q;
+                if (!FUSED && cell < ncells) cells[slot * ncells + cell] = q;
                 sm[slot][ci] = q;
             }
         }
     }
     if (flat) return;
     __syncthreads();
-    if (wave >= S0 && wave <= S1) {
-        const xs_summary q = wave_join(sm[wave][lane]);
-        if (lane == 0) groups[wave * ngroups + g] = q;
+    if constexpr (!FUSED) {
+        if (wave >= S0 && wave <= S1) {
+            const xs_summary q = wave_join(sm[wave][lane]);
+            if (lane == 0) groups[wave * ngroups + g] = q;
+        }
+    } else {
+        // the group's summaries go into the start[] rows (dead since the passes), then the 64 cell summaries and the
+        // group's are written through in one coalesced sweep
+        xs_summary *gq = reinterpret_cast<xs_summary *>(&start[0][0]);  // [2] summaries in 1 KiB
+        if (wave >= S0 && wave <= S1) {
+            const xs_summary q = wave_join(sm[wave][lane]);
+            if (lane == 0) gq[wave] = q;
+        }
+        __syncthreads();
+        const int ccnt = (int)(ncells - g * XS_GROUP < XS_GROUP ? ncells - g * XS_GROUP : XS_GROUP);
+#pragma unroll
+        for (int slot = S0; slot <= S1; ++slot) {
+            xs_store_words_agent(reinterpret_cast<unsigned long long *>(cells + slot * ncells + g * XS_GROUP),
+                                 reinterpret_cast<const unsigned long long *>(&sm[slot][0]), ccnt * 5);
+            if (threadIdx.x < 5)
+                __hip_atomic_store(reinterpret_cast<unsigned long long *>(groups + slot * ngroups + g) + threadIdx.x,
+                                   reinterpret_cast<const unsigned long long *>(gq + slot)[threadIdx.x], __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // every wave's write-through stores have been acknowledged ...
+        __syncthreads();
+        int *last = reinterpret_cast<int *>(&red[0]);            // (red: 4 doubles, dead by now)
+        const int64_t bb = g >> 6;
+        const int     gcnt = (int)(ngroups - bb * 64 < 64 ? ngroups - bb * 64 : 64);
+        if (threadIdx.x == 0) {                                  // ... before the group is counted
+#pragma unroll
+            for (int slot = S0; slot <= S1; ++slot) {
+                const unsigned old = __hip_atomic_fetch_add(ready + (slot - S0) * nbatch + bb, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                last[slot] = old == (unsigned)(gcnt - 1);
+            }
+        }
+        __syncthreads();
+        // The workgroup that completes a batch of 64 groups joins their summaries into the batch's (they are all in memory:
+        // every group was written through before it was counted) and raises the batch's flag for the driver.
+        if (wave >= S0 && wave <= S1 && last[wave]) {
+            xs_summary q = xs_identity();
+            if (lane < gcnt) q = xs_load_agent(groups + wave * ngroups + bb * 64 + lane);
+            const xs_summary j = wave_join(q);
+            if (lane < 5)
+                __hip_atomic_store(reinterpret_cast<unsigned long long *>(batches + (wave - S0) * nbatch + bb) + lane,
+                                   readlane_words(j, lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (lane == 0)
+                __hip_atomic_fetch_add(ready + (wave - S0) * nbatch + bb, XS_BATCH_READY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
+}
+
+template <int KIND, bool FLAT>
+__global__ __launch_bounds__(256) void xs_summarize(int64_t n, const double *__restrict__ a, const double *__restrict__ b,
+                                                   const double *__restrict__ c, int64_t ncells, int64_t ngroups,
+                                                   const double *__restrict__ cellsum, const double *__restrict__ groupsum,
+                                                   const double *__restrict__ gprefix, xs_summary *__restrict__ cells,
+                                                   xs_summary *__restrict__ groups, const double *__restrict__ offsets)
+{
+    __shared__ xsm_shared<(KIND == XS_BOTH_SAME ? 2 : 1)> W;
+    xs_summarize_body<KIND, FLAT, false>(W, blockIdx.x, n, a, b, c, ncells, ngroups, cellsum, groupsum, gprefix, cells, groups, offsets,
+                                         nullptr, nullptr, 0);
 }
 
 // ---------------------------------------------------------------------------------------------- the driver
@@ -898,6 +1009,159 @@ __global__ __launch_bounds__(XD_THREADS) void xs_drive(int64_t n, const double *
     xs_finalize(KIND == XS_L1 ? 0.0 : s_dot, KIND == XS_DOT ? 0.0 : s_l1, mode, hist, iter, tol, done, out);
 }
 
+
+// ---------------------------------------------------------------------------------------------- summaries and walk in ONE launch
+// xs_summarize followed by xs_drive leaves the chip to one workgroup for as long as the summaries took to build (256^3:
+// 52 + 55 us for p.Ap).  xs_fused runs both at once: workgroups 0 (and 1, for the second sum) are DRIVERS, the others
+// summarise one group each, in launch order, and count themselves per batch of 64 groups; a driver takes the batches in
+// order as they fill up, so the walk ends a few microseconds after the last group's summary.
+//   driver = 4 waves: waves 1..3 are STAGERS (stager k owns ring slot k and the batches k, k+3, ...: waits until the
+//   walk has left the slot and the batch's groups are all counted, copies the 64 group summaries into LDS, joins them into
+//   the batch's summary, and fetches ahead what a descent would need: the cell summaries of a group flagged irregular and
+//   the elements of its irregular cells); wave 0 WALKS: per batch one summary to validate and apply, else down into the
+//   groups, the cells, the elements, as xd_sum does.
+// Nothing waits for a driver, and a driver only waits for workgroups that wait for nothing, so the launch always drains;
+// should a count never fill up (it cannot, short of a fault elsewhere) every wait gives up after ~2 s and the sums are NaN.
+constexpr long long XR_PATIENCE = 200000000;  // ticks of the 100 MHz clock
+
+struct xr_shared {
+    double stage[XS_CELL];
+};
+
+template <int KIND>
+__device__ __forceinline__ double xr_chain(xr_shared &S, double s, int slot, int64_t n, const double *__restrict__ a,
+                                           const double *__restrict__ b, const double *__restrict__ c, int64_t cell)
+{
+    const int lane = threadIdx.x & 63;
+    double    t0, t1;
+    xs_cell_terms<KIND>(slot, n, a, b, c, cell, t0, t1);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();  // the previous cell's reads are over
+    *reinterpret_cast<double2 *>(S.stage + 2 * lane) = make_double2(t0, t1);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    return xs_chain(s, S.stage);
+}
+
+// the sum of slot `slot` while the summaries are still being built (one wave)
+template <int KIND>
+__device__ double xr_sum(xr_shared &S, int slot, int64_t n, const double *__restrict__ a, const double *__restrict__ b,
+                         const double *__restrict__ c, int64_t ncells, int64_t ngroups, const xs_summary *__restrict__ cells,
+                         const xs_summary *__restrict__ groups, const xs_summary *__restrict__ batches, unsigned *__restrict__ ready,
+                         long long *trace)
+{
+    const int lane = threadIdx.x & 63;
+    // optional time stamps (tools/trace_fused.py; 100 MHz ticks): [0] start, [8 + b] batch b seen ready, [152 + b] walked
+    const long long tk0 = trace ? wall_clock64() : 0;
+    if (trace && lane == 0) trace[0] = tk0;
+#define XR_STAMP(base, b)                                                                          \
+    do {                                                                                           \
+        if (trace != nullptr && lane == 0 && (b) < 72) trace[(base) + (b)] = wall_clock64() - tk0; \
+    } while (0)
+    cells += slot * ncells;
+    groups += slot * ngroups;
+    const int nb = (int)((ngroups + 63) / 64);
+    double    s = 0.0;
+    int       cur = 0;
+    long long t0 = wall_clock64();
+    while (cur < nb) {
+        // the batches from `cur` on whose summaries are in memory: a prefix of up to 64, taken together
+        const int cnt = nb - cur < 64 ? nb - cur : 64;
+        unsigned  f = 0;
+        if (lane < cnt) f = __hip_atomic_load(ready + cur + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long rdy = __ballot(f >= XS_BATCH_READY);
+        const int                m = ~rdy ? (int)__builtin_ctzll(~rdy) : 64;
+        if (m == 0) {
+            if (wall_clock64() - t0 > XR_PATIENCE) return NAN;
+            __builtin_amdgcn_s_sleep(8);
+            continue;
+        }
+        xs_summary Bq = xs_identity();
+        if (lane < m) {
+            Bq = xs_load_agent(batches + cur + lane);
+            __hip_atomic_store(ready + cur + lane, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // zero for the next launch
+        }
+        for (int q = 0; q < m; ++q) XR_STAMP(8, cur + q);
+        const int64_t Binc = xs_scan(Bq, m);
+        int           tstart = 0;
+        while (tstart < m) {
+            const int fb = xs_batch(Bq, Binc, tstart, m, s);
+            if (fb >= m) break;
+            const int     bb = cur + fb;
+            const int     gcnt = (int)(ngroups - (int64_t)bb * 64 < 64 ? ngroups - (int64_t)bb * 64 : 64);
+            xs_summary    Gq = xs_identity();
+            if (lane < gcnt) Gq = xs_load_agent(groups + (int64_t)bb * 64 + lane);
+            const int64_t Ginc = xs_scan(Gq, gcnt);
+            int           gstart = 0;
+            while (gstart < gcnt) {
+                const int f2 = xs_batch(Gq, Ginc, gstart, gcnt, s);
+                if (f2 >= gcnt) break;
+                const int64_t it = (int64_t)bb * 64 + f2, c0 = it * XS_GROUP;
+                const int     ccnt = (int)(ncells - c0 < XS_GROUP ? ncells - c0 : XS_GROUP);
+                xs_summary    Cq = xs_identity();
+                if (lane < ccnt) Cq = xs_load_agent(cells + c0 + lane);
+                const int64_t Cinc = xs_scan(Cq, ccnt);
+                int           cstart = 0;
+                while (cstart < ccnt) {
+                    const int cf = xs_batch(Cq, Cinc, cstart, ccnt, s);
+                    if (cf >= ccnt) break;
+                    s = xr_chain<KIND>(S, s, slot, n, a, b, c, c0 + cf);
+                    cstart = cf + 1;
+                }
+                gstart = f2 + 1;
+            }
+            XR_STAMP(152, bb);
+            tstart = fb + 1;
+        }
+        cur += m;
+        XR_STAMP(152, cur - 1);
+        t0 = wall_clock64();
+    }
+    return s;
+}
+
+template <int KIND>
+__global__ __launch_bounds__(256) void xs_fused(int64_t n, const double *__restrict__ a, const double *__restrict__ b,
+                                               const double *__restrict__ c, int64_t ncells, int64_t ngroups,
+                                               const double *__restrict__ cellsum, const double *__restrict__ groupsum,
+                                               const double *__restrict__ gprefix, xs_summary *__restrict__ cells,
+                                               xs_summary *__restrict__ groups, xs_summary *__restrict__ batches,
+                                               unsigned *__restrict__ ready, int mode, double *hist, int iter, double tol, int *done,
+                                               double *out, double *xfer, long long *trace)
+{
+    constexpr int S0 = KIND == XS_L1 ? 1 : 0, S1 = KIND == XS_DOT ? 0 : 1, ND = S1 - S0 + 1;
+    typedef xsm_shared<ND> sum_shared;
+    constexpr size_t       LDS = sizeof(sum_shared) > sizeof(xr_shared) ? sizeof(sum_shared) : sizeof(xr_shared);
+    __shared__ __attribute__((aligned(16))) unsigned char raw[LDS];
+    // every workgroup of the launch takes the same side: the flag only changes when a driver finalises, after the last
+    // summary of the launch
+    if (done != nullptr && mode != 3 && mode != 0 && *done != 0) return;
+    const int64_t nbatch = (ngroups + 63) / 64;
+    if (blockIdx.x >= (unsigned)ND) {
+        xs_summarize_body<KIND, false, true>(*reinterpret_cast<sum_shared *>(raw), blockIdx.x - ND, n, a, b, c, ncells, ngroups, cellsum,
+                                             groupsum, gprefix, cells, groups, nullptr, ready, batches, nbatch);
+        return;
+    }
+    if (threadIdx.x >= 64) return;  // a driver is one wave
+    const int    slot = S0 + (int)blockIdx.x;
+    const double s = xr_sum<KIND>(*reinterpret_cast<xr_shared *>(raw), slot, n, a, b, c, ncells, ngroups, cells, groups,
+                                  batches + (slot - S0) * nbatch, ready + (slot - S0) * nbatch, slot == S0 ? trace : nullptr);
+    if (threadIdx.x != 0) return;
+    double s_dot = s, s_l1 = s;
+    if constexpr (S1 > S0) {
+        // two drivers: the second to arrive has both sums (as xs_drive)
+        unsigned long long *tk = reinterpret_cast<unsigned long long *>(xfer + 2);
+        __hip_atomic_store(xfer + slot, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long old = __hip_atomic_fetch_add(tk, 1ull, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (old == 0) return;
+        __hip_atomic_store(tk, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_dot = __hip_atomic_load(xfer + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_l1 = __hip_atomic_load(xfer + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    xs_finalize(KIND == XS_L1 ? 0.0 : s_dot, KIND == XS_DOT ? 0.0 : s_l1, mode, hist, iter, tol, done, out);
+}
+
 // The sums of a vector spread over several ranks, once the last rank's part is in (cgh_xsum_finalize): one thread.
 __global__ void xs_finalize_kernel(const double *__restrict__ sums, int mode, double *hist, int iter, double tol, int *done)
 {
@@ -906,6 +1170,7 @@ __global__ void xs_finalize_kernel(const double *__restrict__ sums, int mode, do
 }
 
 long long *g_xs_prof = nullptr;  // device buffer of 16 words, or NULL (cgh_xsum_set_prof)
+long long *g_xs_trace = nullptr; // device buffer of 224 words, or NULL (cgh_xsum_set_trace): time stamps of the fused driver
 
 template <int KIND>
 int launch_all(cgh_xsum *w, bool presummed, int64_t n, const double *a, const double *b, const double *c, int mode, double *hist, int iter,
@@ -932,6 +1197,13 @@ int launch_all(cgh_xsum *w, bool presummed, int64_t n, const double *a, const do
     }
     const bool  flat = w->ncells <= XD_ITEMS;  // few cells: no group level
     xs_summary *grp = flat ? nullptr : w->groups;
+    if (!flat && s_in == nullptr && s_out == nullptr && g_xs_prof == nullptr && g_cfg.xsum_fused) {
+        constexpr int ND = KIND == XS_BOTH_SAME ? 2 : 1;
+        hipLaunchKernelGGL((xs_fused<KIND>), dim3(ng + ND), dim3(256), 0, s, n, a, b, c, w->ncells, w->ngroups, (const double *)w->cellsum,
+                           gsum, prefix, w->cells, w->groups, w->batches, w->ready, mode, hist, iter, tol, done, out, w->xfer, g_xs_trace);
+        CGH_HIP(hipGetLastError());
+        return CGH_OK;
+    }
     if (flat)
         hipLaunchKernelGGL((xs_summarize<KIND, true>), dim3(4 * ng), dim3(256), 0, s, n, a, b, c, w->ncells, w->ngroups,
                            (const double *)w->cellsum, gsum, prefix, w->cells, grp, s_in);
@@ -966,7 +1238,14 @@ cgh_xsum *cgh_xsum_create(int64_t n)
         cgh_free(w->xfer);
         w->xfer = nullptr;
     }
-    if (!w->cellsum || !w->groupsum || !w->gprefix || !w->cells || !w->groups || !w->xfer) {
+    const size_t nready = 2 * (size_t)((w->ngroups + 63) / 64);
+    w->ready = (unsigned *)cgh_alloc(sizeof(unsigned) * nready);
+    if (w->ready && hipMemset(w->ready, 0, sizeof(unsigned) * nready) != hipSuccess) {
+        cgh_free(w->ready);
+        w->ready = nullptr;
+    }
+    w->batches = (xs_summary *)cgh_alloc(sizeof(xs_summary) * nready);
+    if (!w->cellsum || !w->groupsum || !w->gprefix || !w->cells || !w->groups || !w->xfer || !w->ready || !w->batches) {
         cgh_xsum_free(w);
         return nullptr;
     }
@@ -982,10 +1261,13 @@ void cgh_xsum_free(cgh_xsum *w)
     cgh_free(w->cells);
     cgh_free(w->groups);
     cgh_free(w->xfer);
+    cgh_free(w->ready);
+    cgh_free(w->batches);
     delete w;
 }
 
 // Profile of the serial walks that follow (see XS_PROF_ADD): 16 zeroed 64-bit words of device memory, or NULL to stop.
+extern "C" void cgh_xsum_set_trace(void *dev_224_words) { g_xs_trace = (long long *)dev_224_words; }
 extern "C" void cgh_xsum_set_prof(void *dev_16_words) { g_xs_prof = (long long *)dev_16_words; }
 
 double *cgh_xsum_cellsums(cgh_xsum *w) { return w ? w->cellsum : nullptr; }
