@@ -140,6 +140,62 @@ def test_random_trials_device(cga, monkeypatch):
         assert eq(v[0], O.lib().orc_vec_l1norm(O.D(t), n)), (trial, n, kind)
 
 
+def _hard_cases(rng):
+    """adversarial inputs at the sizes that take the one-launch path (xs_fused: summaries and walk at once; > 2048 cells)"""
+    n = 300000 + 77
+    yield "cancellation", np.tile([1e16, 1.0, -1e16, 3.0], n // 4 + 1)[:n] * (1.0 + 1e-3 * rng.random(n))
+    t = np.full(n, 2.0 ** -30); t[::4097] = -(2.0 ** -18)
+    yield "sawtooth around a power of two", np.concatenate([[1.0 - 2.0 ** -20], t])
+    yield "all ties", np.round(rng.standard_normal(700001) * 1024) / 1024
+    t = rng.random(900000) * 2.0 ** -60; t[450000] = 1.0; t[450001:] *= 2.0 ** 58
+    yield "tiny, then one large element, then comparable ones", t
+    t = rng.random(400000); t[:270000] = 0.0
+    yield "zero prefix over many groups", t
+    t = rng.random(400000); t[123457] = np.inf
+    yield "inf in the middle", t
+    t = rng.random(400000); t[399999] = np.nan
+    yield "nan at the end", t
+    t = rng.standard_normal(64 * 64 * 128 * 3 + 1)
+    yield "three full batches and one element", t
+    yield "exactly two batches", rng.random(64 * 64 * 128 * 2) + 0.5
+    yield "subnormal start", np.concatenate([np.full(300000, 5e-324), rng.random(100000) * 1e-300])
+
+
+def test_fused_launch_hard_inputs_and_unfused_twin(cga, monkeypatch):
+    """the one-launch path against the sequential sum, and against the two-launch path (CGH_XSUM_FUSED=0) bit for bit"""
+    rng = np.random.default_rng(77)
+    for name, t in _hard_cases(rng):
+        t = np.ascontiguousarray(t, dtype=np.float64)
+        n = t.size
+        dt = cga.DeviceVector.from_host(t); d1 = cga.DeviceVector.from_host(np.ones(n))
+        got = {}
+        for fused in ("1", "0"):
+            setknob(monkeypatch, "CGH_XSUM_FUSED", fused)
+            v = np.zeros(3)
+            cga.binding.check(cga.lib().cgh_dot(dt.ptr, d1.ptr, n, 1, O.D(v[0:1])))
+            cga.binding.check(cga.lib().cgh_dot(dt.ptr, dt.ptr, n, 1, O.D(v[1:2])))
+            cga.binding.check(cga.lib().cgh_l1norm(dt.ptr, n, 1, O.D(v[2:3])))
+            got[fused] = v
+        want = (seq_sum(t), O.lib().orc_vec_dot(O.D(t), O.D(t), n), O.lib().orc_vec_l1norm(O.D(t), n))
+        for k in range(3):
+            assert eq(got["1"][k], want[k]), (name, k, got["1"][k], want[k])
+            assert eq(got["0"][k], want[k]), (name, k, "two launches")
+    setknob(monkeypatch, "CGH_XSUM_FUSED", "1")
+
+
+def test_fused_launch_more_than_64_batches(cga):
+    """34M elements: 65 batches of 64 groups (the driver takes at most 64 at a time) and the group-prefix scan kernel"""
+    rng = np.random.default_rng(78)
+    n = 64 * 64 * 64 * 128 + 500001
+    t = rng.random(n) + 0.25
+    dt = cga.DeviceVector.from_host(t)
+    v = np.zeros(1)
+    cga.binding.check(cga.lib().cgh_dot(dt.ptr, dt.ptr, n, 1, O.D(v)))
+    assert eq(v[0], O.lib().orc_vec_dot(O.D(t), O.D(t), n))
+    cga.binding.check(cga.lib().cgh_l1norm(dt.ptr, n, 1, O.D(v)))
+    assert eq(v[0], O.lib().orc_vec_l1norm(O.D(t), n))
+
+
 @pytest.mark.parametrize("shape", [(17, 17, 17), (20, 20, 11), (32, 32, 8), (64, 64, 33)])
 def test_strict_cg_shapes_around_the_fused_paths(cga, shape):
     """default thresholds; n odd (scalar SpMV path, odd tail in the cell sums), n even but not a multiple of 128 (no
