@@ -558,6 +558,41 @@ __device__ __forceinline__ void xs_summarize_body(xsm_shared<(KIND == XS_BOTH_SA
             }
         }
     }
+    if constexpr (FLAT && FUSED) {
+        // few cells, one launch: a batch is the 64 cells of one group, summarised by four workgroups of 16 cells each
+        __syncthreads();
+        const int     pass = (int)(bid & 3);
+        const int64_t c0 = g * XS_GROUP + pass * 16;
+        const int     ccnt = (int)(ncells - c0 < 16 ? (ncells - c0 < 0 ? 0 : ncells - c0) : 16);
+#pragma unroll
+        for (int slot = S0; slot <= S1; ++slot)
+            xs_store_words_agent(reinterpret_cast<unsigned long long *>(cells + slot * ncells + c0),
+                                 reinterpret_cast<const unsigned long long *>(&sm[slot][pass * 16]), ccnt * 5);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __syncthreads();
+        int *last = reinterpret_cast<int *>(&red[0]);
+        if (threadIdx.x == 0) {
+#pragma unroll
+            for (int slot = S0; slot <= S1; ++slot) {
+                const unsigned old = __hip_atomic_fetch_add(ready + (slot - S0) * nbatch + g, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                last[slot] = old == 3u;
+            }
+        }
+        __syncthreads();
+        if (wave >= S0 && wave <= S1 && last[wave]) {
+            const int  gc = (int)(ncells - g * XS_GROUP < XS_GROUP ? ncells - g * XS_GROUP : XS_GROUP);
+            xs_summary q = xs_identity();
+            if (lane < gc) q = xs_load_agent(cells + wave * ncells + g * XS_GROUP + lane);
+            const xs_summary j = wave_join(q);
+            if (lane < 5)
+                __hip_atomic_store(reinterpret_cast<unsigned long long *>(batches + (wave - S0) * nbatch + g) + lane, readlane_words(j, lane),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (lane == 0)
+                __hip_atomic_fetch_add(ready + (wave - S0) * nbatch + g, XS_BATCH_READY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        return;
+    }
     if (flat) return;
     __syncthreads();
     if constexpr (!FUSED) {
@@ -1044,8 +1079,8 @@ __device__ __forceinline__ double xr_chain(xr_shared &S, double s, int slot, int
     return xs_chain(s, S.stage);
 }
 
-// the sum of slot `slot` while the summaries are still being built (one wave)
-template <int KIND>
+// the sum of slot `slot` while the summaries are still being built (one wave).  FLAT: no group level, a batch is 64 cells.
+template <int KIND, bool FLAT>
 __device__ double xr_sum(xr_shared &S, int slot, int64_t n, const double *__restrict__ a, const double *__restrict__ b,
                          const double *__restrict__ c, int64_t ncells, int64_t ngroups, const xs_summary *__restrict__ cells,
                          const xs_summary *__restrict__ groups, const xs_summary *__restrict__ batches, unsigned *__restrict__ ready,
@@ -1060,8 +1095,8 @@ __device__ double xr_sum(xr_shared &S, int slot, int64_t n, const double *__rest
         if (trace != nullptr && lane == 0 && (b) < 72) trace[(base) + (b)] = wall_clock64() - tk0; \
     } while (0)
     cells += slot * ncells;
-    groups += slot * ngroups;
-    const int nb = (int)((ngroups + 63) / 64);
+    if (!FLAT) groups += slot * ngroups;
+    const int nb = FLAT ? (int)ngroups : (int)((ngroups + 63) / 64);
     double    s = 0.0;
     int       cur = 0;
     long long t0 = wall_clock64();
@@ -1088,16 +1123,9 @@ __device__ double xr_sum(xr_shared &S, int slot, int64_t n, const double *__rest
         while (tstart < m) {
             const int fb = xs_batch(Bq, Binc, tstart, m, s);
             if (fb >= m) break;
-            const int     bb = cur + fb;
-            const int     gcnt = (int)(ngroups - (int64_t)bb * 64 < 64 ? ngroups - (int64_t)bb * 64 : 64);
-            xs_summary    Gq = xs_identity();
-            if (lane < gcnt) Gq = xs_load_agent(groups + (int64_t)bb * 64 + lane);
-            const int64_t Ginc = xs_scan(Gq, gcnt);
-            int           gstart = 0;
-            while (gstart < gcnt) {
-                const int f2 = xs_batch(Gq, Ginc, gstart, gcnt, s);
-                if (f2 >= gcnt) break;
-                const int64_t it = (int64_t)bb * 64 + f2, c0 = it * XS_GROUP;
+            const int bb = cur + fb;
+            if constexpr (FLAT) {
+                const int64_t c0 = (int64_t)bb * XS_GROUP;
                 const int     ccnt = (int)(ncells - c0 < XS_GROUP ? ncells - c0 : XS_GROUP);
                 xs_summary    Cq = xs_identity();
                 if (lane < ccnt) Cq = xs_load_agent(cells + c0 + lane);
@@ -1109,7 +1137,29 @@ __device__ double xr_sum(xr_shared &S, int slot, int64_t n, const double *__rest
                     s = xr_chain<KIND>(S, s, slot, n, a, b, c, c0 + cf);
                     cstart = cf + 1;
                 }
-                gstart = f2 + 1;
+            } else {
+                const int     gcnt = (int)(ngroups - (int64_t)bb * 64 < 64 ? ngroups - (int64_t)bb * 64 : 64);
+                xs_summary    Gq = xs_identity();
+                if (lane < gcnt) Gq = xs_load_agent(groups + (int64_t)bb * 64 + lane);
+                const int64_t Ginc = xs_scan(Gq, gcnt);
+                int           gstart = 0;
+                while (gstart < gcnt) {
+                    const int f2 = xs_batch(Gq, Ginc, gstart, gcnt, s);
+                    if (f2 >= gcnt) break;
+                    const int64_t it = (int64_t)bb * 64 + f2, c0 = it * XS_GROUP;
+                    const int     ccnt = (int)(ncells - c0 < XS_GROUP ? ncells - c0 : XS_GROUP);
+                    xs_summary    Cq = xs_identity();
+                    if (lane < ccnt) Cq = xs_load_agent(cells + c0 + lane);
+                    const int64_t Cinc = xs_scan(Cq, ccnt);
+                    int           cstart = 0;
+                    while (cstart < ccnt) {
+                        const int cf = xs_batch(Cq, Cinc, cstart, ccnt, s);
+                        if (cf >= ccnt) break;
+                        s = xr_chain<KIND>(S, s, slot, n, a, b, c, c0 + cf);
+                        cstart = cf + 1;
+                    }
+                    gstart = f2 + 1;
+                }
             }
             XR_STAMP(152, bb);
             tstart = fb + 1;
@@ -1121,7 +1171,7 @@ __device__ double xr_sum(xr_shared &S, int slot, int64_t n, const double *__rest
     return s;
 }
 
-template <int KIND>
+template <int KIND, bool FLAT>
 __global__ __launch_bounds__(256) void xs_fused(int64_t n, const double *__restrict__ a, const double *__restrict__ b,
                                                const double *__restrict__ c, int64_t ncells, int64_t ngroups,
                                                const double *__restrict__ cellsum, const double *__restrict__ groupsum,
@@ -1137,15 +1187,15 @@ __global__ __launch_bounds__(256) void xs_fused(int64_t n, const double *__restr
     // every workgroup of the launch takes the same side: the flag only changes when a driver finalises, after the last
     // summary of the launch
     if (done != nullptr && mode != 3 && mode != 0 && *done != 0) return;
-    const int64_t nbatch = (ngroups + 63) / 64;
+    const int64_t nbatch = FLAT ? ngroups : (ngroups + 63) / 64;
     if (blockIdx.x >= (unsigned)ND) {
-        xs_summarize_body<KIND, false, true>(*reinterpret_cast<sum_shared *>(raw), blockIdx.x - ND, n, a, b, c, ncells, ngroups, cellsum,
+        xs_summarize_body<KIND, FLAT, true>(*reinterpret_cast<sum_shared *>(raw), blockIdx.x - ND, n, a, b, c, ncells, ngroups, cellsum,
                                              groupsum, gprefix, cells, groups, nullptr, ready, batches, nbatch);
         return;
     }
     if (threadIdx.x >= 64) return;  // a driver is one wave
     const int    slot = S0 + (int)blockIdx.x;
-    const double s = xr_sum<KIND>(*reinterpret_cast<xr_shared *>(raw), slot, n, a, b, c, ncells, ngroups, cells, groups,
+    const double s = xr_sum<KIND, FLAT>(*reinterpret_cast<xr_shared *>(raw), slot, n, a, b, c, ncells, ngroups, cells, groups,
                                   batches + (slot - S0) * nbatch, ready + (slot - S0) * nbatch, slot == S0 ? trace : nullptr);
     if (threadIdx.x != 0) return;
     double s_dot = s, s_l1 = s;
@@ -1197,10 +1247,16 @@ int launch_all(cgh_xsum *w, bool presummed, int64_t n, const double *a, const do
     }
     const bool  flat = w->ncells <= XD_ITEMS;  // few cells: no group level
     xs_summary *grp = flat ? nullptr : w->groups;
-    if (!flat && s_in == nullptr && s_out == nullptr && g_xs_prof == nullptr && g_cfg.xsum_fused) {
+    if (s_in == nullptr && s_out == nullptr && g_xs_prof == nullptr && g_cfg.xsum_fused) {
         constexpr int ND = KIND == XS_BOTH_SAME ? 2 : 1;
-        hipLaunchKernelGGL((xs_fused<KIND>), dim3(ng + ND), dim3(256), 0, s, n, a, b, c, w->ncells, w->ngroups, (const double *)w->cellsum,
-                           gsum, prefix, w->cells, w->groups, w->batches, w->ready, mode, hist, iter, tol, done, out, w->xfer, g_xs_trace);
+        if (flat)
+            hipLaunchKernelGGL((xs_fused<KIND, true>), dim3(4 * ng + ND), dim3(256), 0, s, n, a, b, c, w->ncells, w->ngroups,
+                               (const double *)w->cellsum, gsum, prefix, w->cells, w->groups, w->batches, w->ready, mode, hist, iter, tol, done,
+                               out, w->xfer, g_xs_trace);
+        else
+            hipLaunchKernelGGL((xs_fused<KIND, false>), dim3(ng + ND), dim3(256), 0, s, n, a, b, c, w->ncells, w->ngroups,
+                               (const double *)w->cellsum, gsum, prefix, w->cells, w->groups, w->batches, w->ready, mode, hist, iter, tol, done,
+                               out, w->xfer, g_xs_trace);
         CGH_HIP(hipGetLastError());
         return CGH_OK;
     }
@@ -1238,7 +1294,7 @@ cgh_xsum *cgh_xsum_create(int64_t n)
         cgh_free(w->xfer);
         w->xfer = nullptr;
     }
-    const size_t nready = 2 * (size_t)((w->ngroups + 63) / 64);
+    const size_t nready = 2 * (size_t)((w->ngroups + 63) / 64 > 32 ? (w->ngroups + 63) / 64 : 32);  // (few cells: one batch per group, <= 32)
     w->ready = (unsigned *)cgh_alloc(sizeof(unsigned) * nready);
     if (w->ready && hipMemset(w->ready, 0, sizeof(unsigned) * nready) != hipSuccess) {
         cgh_free(w->ready);

@@ -25,8 +25,9 @@ L.cgh_xsum_set_trace(tr.ptr)
 cga.check(L.cgh_dot(a.ptr, b.ptr, n, 1, C.byref(out)))
 L.cgh_xsum_set_trace(None)
 t = tr.to_host().view(np.int64)
-nb = ((n + 127) // 128 + 63) // 64
-nb = (nb + 63) // 64
+ncells = (n + 127) // 128
+ngroups = (ncells + 63) // 64
+nb = ngroups if ncells <= 2048 else (ngroups + 63) // 64   # few cells: a batch is one group of 64 cells
 print("n=%d batches=%d  (us after the driver's start)" % (n, nb))
 for bb in range(min(nb, 72)):
     print("batch %2d  seen ready %7.2f  walked %7.2f" % (bb, t[8 + bb] / 100.0, t[152 + bb] / 100.0))
