@@ -104,9 +104,11 @@ struct cgh_solver {
 
 // The strict-mode sums of the solver (modes: see seq_sums): parallel order-exact sums for long vectors, one lane otherwise.
 static int strict_sums(cgh_solver *sv, const double *a, const double *b, const double *c, int mode, int iter, hipStream_t s,
-                       bool presummed = false)
+                       bool presummed = false, double *xu_x = nullptr, const double *xu_p = nullptr, bool *xu_taken = nullptr)
 {
-    if (sv->xs) return cgh_xsum_launch(sv->xs, sv->n, a, b, c, mode, sv->hist, iter, sv->tol, sv->done, nullptr, s, presummed);
+    if (xu_taken) *xu_taken = false;
+    if (sv->xs)
+        return cgh_xsum_launch(sv->xs, sv->n, a, b, c, mode, sv->hist, iter, sv->tol, sv->done, nullptr, s, presummed, xu_x, xu_p, xu_taken);
     hipLaunchKernelGGL(seq_sums, dim3(1), dim3(CGH_BLOCK), 0, s, sv->n, a, b, c, mode, sv->hist, iter, sv->tol, sv->done,
                        (double *)nullptr);
     return CGH_OK;
@@ -313,9 +315,11 @@ static int enqueue_iterations(cgh_solver *sv, int count, int time_kernels, bool 
             hipLaunchKernelGGL((cg_update_r<1, 3>), dim3(vg), dim3(CGH_BLOCK), 0, s, n, dr, (const double *)dAp,
                                (const double *)dA, gridA, dB, dh, iter, (const int *)dd, rev2, (const double *)nullptr,
                                cgh_xsum_cellsums(sv->xs), cgh_xsum_cells(sv->xs));
-            rc = strict_sums(sv, dr, dr, dr, 2, iter, s, sv->xs != nullptr);
+            // ... and the launch of the sums of r may take x += alpha p along (xsum.hip, xs_fused): then K3 only updates p
+            bool x_done = false;
+            rc = strict_sums(sv, dr, dr, dr, 2, iter, s, sv->xs != nullptr, d_x, dp, &x_done);
             if (rc) return rc;
-            hipLaunchKernelGGL((cg_update_xp<1, 3>), dim3(vg), dim3(CGH_BLOCK), 0, s, n, d_x, (const double *)dr, dp,
+            hipLaunchKernelGGL((cg_update_xp<1, 3>), dim3(vg), dim3(CGH_BLOCK), 0, s, n, x_done ? (double *)nullptr : d_x, (const double *)dr, dp,
                                (const double *)dB, vg, dh, iter, tol, dd, rev1, (const double *)nullptr);
         } else {
             // non-temporal loads + x store (3) unless the working set is within twice the Infinity Cache (0): see cgh_fits_llc

@@ -158,6 +158,7 @@ __global__ __launch_bounds__(CGH_BLOCK) void cg_update_r(int64_t n, double *__re
 }
 
 // K3.  x += alpha p (alpha of this iteration, from the history); then the convergence test, beta, p = r + beta p.
+// x == NULL: x has been updated already (strict mode: by the launch of the sums of r, xsum.hip).
 template <int MODE, int VV>
 __global__ __launch_bounds__(CGH_BLOCK) void cg_update_xp(int64_t n, double *__restrict__ x, const double *__restrict__ r,
                                                          double *__restrict__ p, const double *__restrict__ partials, int count,
@@ -206,6 +207,7 @@ __global__ __launch_bounds__(CGH_BLOCK) void cg_update_xp(int64_t n, double *__r
         // nothing.  Every workgroup reaches the same verdict from the same partials; workgroup 0 publishes it, and no
         // workgroup of THIS launch reads it back.
         if (STRICT == false && blockIdx.x == 0 && threadIdx.x == 0) *done = iter;
+        if (x == nullptr) return;
         for (int64_t cc = blockIdx.x; cc < chunks; cc += gridDim.x) {
             const int64_t k = cc * CGH_BLOCK + threadIdx.x;
             if (k >= pairs) continue;
@@ -218,15 +220,17 @@ __global__ __launch_bounds__(CGH_BLOCK) void cg_update_xp(int64_t n, double *__r
     for (int64_t cc = blockIdx.x; cc < chunks; cc += gridDim.x) {
         const int64_t k = (rev ? chunks - 1 - cc : cc) * CGH_BLOCK + threadIdx.x;
         if (k >= pairs) continue;
-        const double2 xv = ld2<VV>(x, k);
         const double2 rv = ld2<VV>(r, k);
         const double2 pv = ld2<VV>(p, k);
         // reference vec_axpy: out = a + alpha*b (vec.c:88-94): x += alpha p (cg.c:467), p = r + beta p (cg.c:489)
-        st2<(VV & 2) != 0>(x, k, madd_rn(xv.x, alpha, pv.x), madd_rn(xv.y, alpha, pv.y));
+        if (x != nullptr) {
+            const double2 xv = ld2<VV>(x, k);
+            st2<(VV & 2) != 0>(x, k, madd_rn(xv.x, alpha, pv.x), madd_rn(xv.y, alpha, pv.y));
+        }
         st2<(VV & 8) != 0>(p, k, madd_rn(rv.x, beta, pv.x), madd_rn(rv.y, beta, pv.y));
     }
     if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
-        x[n - 1] = madd_rn(x[n - 1], alpha, p[n - 1]);
+        if (x != nullptr) x[n - 1] = madd_rn(x[n - 1], alpha, p[n - 1]);
         p[n - 1] = madd_rn(r[n - 1], beta, p[n - 1]);
     }
 }

@@ -29,6 +29,7 @@ static void read_env_knobs()
     if (g_cfg.csr_window != 512 && g_cfg.csr_window != 2048) g_cfg.csr_window = 1024;
     g_cfg.csr_exact = env_int("CGH_CSR_EXACT", g_cfg.csr_exact);
     if (getenv("CGH_XSUM_MIN_ROWS")) g_cfg.xsum_min_rows = atoll(getenv("CGH_XSUM_MIN_ROWS"));
+    g_cfg.xsum_xupd = env_int("CGH_XSUM_XUPD", g_cfg.xsum_xupd);
     g_cfg.xsum_fused = env_int("CGH_XSUM_FUSED", g_cfg.xsum_fused);
     g_cfg.serpentine = env_int("CGH_SERPENTINE", g_cfg.serpentine);
     g_cfg.vec_variant = env_int("CGH_VEC_VARIANT", g_cfg.vec_variant);

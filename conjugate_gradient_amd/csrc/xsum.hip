@@ -1171,6 +1171,36 @@ __device__ double xr_sum(xr_shared &S, int slot, int64_t n, const double *__rest
     return s;
 }
 
+// x[i] += alpha p[i] for the rows of four groups (4 x 8192), alpha of the iteration in flight from the history: the
+// arithmetic of cg_update_xp (reference vec_axpy, vec.c:88-94: rounded product, rounded sum)
+typedef double xd2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void xs_update_x(int64_t n, double *__restrict__ x, const double *__restrict__ p, const double *hist, int iter,
+                                            const int *done, unsigned k)
+{
+    if (iter == 0) iter = done[1];  // replayed launches: the iteration number comes from the device (as xs_finalize)
+    const double  alpha = hist[(size_t)iter * CGH_HIST + 2];
+    const int64_t e0 = (int64_t)k * 4 * XS_GROUP * XS_CELL, e1 = e0 + 4 * XS_GROUP * XS_CELL < n ? e0 + 4 * XS_GROUP * XS_CELL : n;
+    const int64_t j1 = e1 >> 1;
+    for (int64_t j = (e0 >> 1) + threadIdx.x; j < j1; j += 4 * 256) {
+        xd2_t xv[4], pv[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (j + q * 256 < j1) {
+                xv[q] = __builtin_nontemporal_load(reinterpret_cast<const xd2_t *>(x) + j + q * 256);
+                pv[q] = reinterpret_cast<const xd2_t *>(p)[j + q * 256];
+            }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (j + q * 256 < j1) {
+                xd2_t o;
+                o.x = madd_rn(xv[q].x, alpha, pv[q].x);
+                o.y = madd_rn(xv[q].y, alpha, pv[q].y);
+                __builtin_nontemporal_store(o, reinterpret_cast<xd2_t *>(x) + j + q * 256);
+            }
+    }
+    if ((n & 1) && e1 == n && e0 < n && threadIdx.x == 0) x[n - 1] = madd_rn(x[n - 1], alpha, p[n - 1]);
+}
+
 template <int KIND, bool FLAT>
 __global__ __launch_bounds__(256) void xs_fused(int64_t n, const double *__restrict__ a, const double *__restrict__ b,
                                                const double *__restrict__ c, int64_t ncells, int64_t ngroups,
@@ -1178,7 +1208,7 @@ __global__ __launch_bounds__(256) void xs_fused(int64_t n, const double *__restr
                                                const double *__restrict__ gprefix, xs_summary *__restrict__ cells,
                                                xs_summary *__restrict__ groups, xs_summary *__restrict__ batches,
                                                unsigned *__restrict__ ready, int mode, double *hist, int iter, double tol, int *done,
-                                               double *out, double *xfer, long long *trace)
+                                               double *out, double *xfer, long long *trace, double *xu_x, const double *xu_p)
 {
     constexpr int S0 = KIND == XS_L1 ? 1 : 0, S1 = KIND == XS_DOT ? 0 : 1, ND = S1 - S0 + 1;
     typedef xsm_shared<ND> sum_shared;
@@ -1189,8 +1219,23 @@ __global__ __launch_bounds__(256) void xs_fused(int64_t n, const double *__restr
     if (done != nullptr && mode != 3 && mode != 0 && *done != 0) return;
     const int64_t nbatch = FLAT ? ngroups : (ngroups + 63) / 64;
     if (blockIdx.x >= (unsigned)ND) {
-        xs_summarize_body<KIND, FLAT, true>(*reinterpret_cast<sum_shared *>(raw), blockIdx.x - ND, n, a, b, c, ncells, ngroups, cellsum,
-                                             groupsum, gprefix, cells, groups, nullptr, ready, batches, nbatch);
+        unsigned sb = blockIdx.x - ND;  // the workgroup's number among those that are no drivers
+        if constexpr (KIND == XS_BOTH_SAME && !FLAT) {
+            // The summaries of r.r and |r|_1 are bound by their arithmetic (134 MB in 65 us), so the launch also carries the
+            // x += alpha p of the same CG iteration (cg.c:467 of the reference), which is pure bandwidth: every fifth
+            // workgroup updates the x of four groups' rows instead of summarising (cg_update_xp then leaves x alone).
+            if (xu_x != nullptr) {
+                const unsigned k = sb / 5, r = sb % 5;
+                if (r == 4) {
+                    xs_update_x(n, xu_x, xu_p, hist, iter, done, k);
+                    return;
+                }
+                sb = k * 4 + r;
+                if ((int64_t)sb >= ngroups) return;
+            }
+        }
+        xs_summarize_body<KIND, FLAT, true>(*reinterpret_cast<sum_shared *>(raw), sb, n, a, b, c, ncells, ngroups, cellsum, groupsum, gprefix,
+                                             cells, groups, nullptr, ready, batches, nbatch);
         return;
     }
     if (threadIdx.x >= 64) return;  // a driver is one wave
@@ -1224,8 +1269,10 @@ long long *g_xs_trace = nullptr; // device buffer of 224 words, or NULL (cgh_xsu
 
 template <int KIND>
 int launch_all(cgh_xsum *w, bool presummed, int64_t n, const double *a, const double *b, const double *c, int mode, double *hist, int iter,
-               double tol, int *done, double *out, hipStream_t s, const double *s_in = nullptr, double *s_out = nullptr)
+               double tol, int *done, double *out, hipStream_t s, const double *s_in = nullptr, double *s_out = nullptr,
+               double *xu_x = nullptr, const double *xu_p = nullptr, bool *xu_taken = nullptr)
 {
+    if (xu_taken) *xu_taken = false;
     const unsigned ng = (unsigned)w->ngroups;
     const double *gsum = w->groupsum;
     if (presummed && w->ncells <= 4096) {
@@ -1249,14 +1296,17 @@ int launch_all(cgh_xsum *w, bool presummed, int64_t n, const double *a, const do
     xs_summary *grp = flat ? nullptr : w->groups;
     if (s_in == nullptr && s_out == nullptr && g_xs_prof == nullptr && g_cfg.xsum_fused) {
         constexpr int ND = KIND == XS_BOTH_SAME ? 2 : 1;
+        // x += alpha p rides along with the sums of r (mode 2, both sums, group level): see xs_fused
+        const bool xu = KIND == XS_BOTH_SAME && !flat && mode == 2 && xu_x != nullptr && xu_p != nullptr && g_cfg.xsum_xupd;
+        if (xu_taken) *xu_taken = xu;
         if (flat)
             hipLaunchKernelGGL((xs_fused<KIND, true>), dim3(4 * ng + ND), dim3(256), 0, s, n, a, b, c, w->ncells, w->ngroups,
                                (const double *)w->cellsum, gsum, prefix, w->cells, w->groups, w->batches, w->ready, mode, hist, iter, tol, done,
-                               out, w->xfer, g_xs_trace);
+                               out, w->xfer, g_xs_trace, (double *)nullptr, (const double *)nullptr);
         else
-            hipLaunchKernelGGL((xs_fused<KIND, false>), dim3(ng + ND), dim3(256), 0, s, n, a, b, c, w->ncells, w->ngroups,
-                               (const double *)w->cellsum, gsum, prefix, w->cells, w->groups, w->batches, w->ready, mode, hist, iter, tol, done,
-                               out, w->xfer, g_xs_trace);
+            hipLaunchKernelGGL((xs_fused<KIND, false>), dim3(xu ? 5 * ((ng + 3) / 4) + ND : ng + ND), dim3(256), 0, s, n, a, b, c, w->ncells,
+                               w->ngroups, (const double *)w->cellsum, gsum, prefix, w->cells, w->groups, w->batches, w->ready, mode, hist, iter,
+                               tol, done, out, w->xfer, g_xs_trace, xu ? xu_x : nullptr, xu ? xu_p : nullptr);
         CGH_HIP(hipGetLastError());
         return CGH_OK;
     }
@@ -1351,8 +1401,10 @@ int cgh_xsum_finalize(const double *sums, int mode, double *hist, int iter, doub
 }
 
 int cgh_xsum_launch(cgh_xsum *w, int64_t n, const double *a, const double *b, const double *c, int mode, double *hist,
-                    int iter, double tol, int *done, double *out, hipStream_t s, bool presummed)
+                    int iter, double tol, int *done, double *out, hipStream_t s, bool presummed, double *xu_x, const double *xu_p,
+                    bool *xu_taken)
 {
+    if (xu_taken) *xu_taken = false;
     if (!w || n != w->n) {
         cgh_set_error("cgh_xsum_launch: workspace was created for another length");
         return CGH_EINVAL;
@@ -1365,7 +1417,8 @@ int cgh_xsum_launch(cgh_xsum *w, int64_t n, const double *a, const double *b, co
     }
     if (a && b && !c) return launch_all<XS_DOT>(w, presummed, n, a, b, c, mode, hist, iter, tol, done, out, s);
     if (!a && !b && c) return launch_all<XS_L1>(w, presummed, n, a, b, c, mode, hist, iter, tol, done, out, s);
-    if (a && a == b && a == c) return launch_all<XS_BOTH_SAME>(w, presummed, n, a, b, c, mode, hist, iter, tol, done, out, s);
+    if (a && a == b && a == c)
+        return launch_all<XS_BOTH_SAME>(w, presummed, n, a, b, c, mode, hist, iter, tol, done, out, s, nullptr, nullptr, xu_x, xu_p, xu_taken);
     cgh_set_error("cgh_xsum_launch: unsupported operand combination");
     return CGH_EINVAL;
 }
