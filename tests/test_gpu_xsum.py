@@ -196,6 +196,30 @@ def test_fused_launch_more_than_64_batches(cga):
     assert eq(v[0], O.lib().orc_vec_l1norm(O.D(t), n))
 
 
+def test_strict_cg_same_bits_with_and_without_the_fused_launches(cga, monkeypatch):
+    """a strict solve that converges, above the group-level threshold (307 200 rows, odd variant too): sums in one launch
+    with x += alpha p riding along (default), without the x update, and as two launches -- history, return value and x
+    bit-identical (the converging iteration still gets its x update, later iterations none)"""
+    for shape in ((80, 80, 48), (81, 79, 49)):
+        n = shape[0] * shape[1] * shape[2]
+        got = []
+        for knobs in ({"CGH_XSUM_FUSED": "1", "CGH_XSUM_XUPD": "1"}, {"CGH_XSUM_FUSED": "1", "CGH_XSUM_XUPD": "0"},
+                      {"CGH_XSUM_FUSED": "0", "CGH_XSUM_XUPD": "1"}):
+            for k, v in knobs.items():
+                setknob(monkeypatch, k, v)
+            b = cga.DeviceVector(n); x = cga.DeviceVector(n)
+            A = cga.Matrix.poisson(*shape, 7, 0x5EED0001, cga.LAYOUT_ELL, b)
+            rep, hist = cga.cg_solve(A, b, x, max_iter=400, tol=1e-3, strict=1, check_every=16)
+            got.append((rep.ret, hist.copy(), x.to_host()))
+        assert 1 < got[0][0] < 400                        # converged well before max_iter: iterations were queued past it
+        for other in got[1:]:
+            assert other[0] == got[0][0]
+            assert same_bits_nan(other[1], got[0][1])
+            assert np.array_equal(bits(other[2]), bits(got[0][2]))
+    setknob(monkeypatch, "CGH_XSUM_FUSED", "1")
+    setknob(monkeypatch, "CGH_XSUM_XUPD", "1")
+
+
 @pytest.mark.parametrize("shape", [(17, 17, 17), (20, 20, 11), (32, 32, 8), (64, 64, 33)])
 def test_strict_cg_shapes_around_the_fused_paths(cga, shape):
     """default thresholds; n odd (scalar SpMV path, odd tail in the cell sums), n even but not a multiple of 128 (no
