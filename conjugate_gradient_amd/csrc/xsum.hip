@@ -425,6 +425,21 @@ __device__ __forceinline__ void xs_summarize_body(xsm_shared<(KIND == XS_BOTH_SA
     // the whole problem is then a handful of workgroups, and their serial depth is what counts
     constexpr bool flat = FLAT;  // (groups == NULL)
     const int64_t g = flat ? bid >> 2 : bid;
+    const int sub = threadIdx.x & 15;  // position inside the cell's 16 lanes
+    const int pass_lo = flat ? (int)(bid & 3) : 0, pass_hi = flat ? pass_lo + 1 : 4;
+    // Loads are coalesced -- load j of a lane fetches elements 32 j + 2 sub, + 1 of its cell, so 16 lanes read 256
+    // contiguous bytes (8 consecutive elements per lane, the layout the scan wants, made every load touch 64 different
+    // lines: 3.8 TB/s at best) -- and the terms go through LDS to reach the lane that scans them: lane r of the cell owns
+    // elements 8 r .. 8 r + 7, rows of 10 doubles keep the 16-byte accesses conflict-free.  The next pass's loads are
+    // issued before this pass is worked on.
+    double *const mine = tr[0][wave] + (threadIdx.x & 48) * 10;  // this cell's 16 rows (slot 0)
+    double2       u[4], v[4];
+    auto fetch = [&](int pass) {
+        const int64_t cell = g * XS_GROUP + pass * 16 + (threadIdx.x >> 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) xs_raw<KIND>(cell < ncells ? n : 0, a, b, c, cell * XS_CELL + 32 * j + 2 * sub, u[j], v[j]);
+    };
+    fetch(pass_lo);  // (first: these loads do not depend on the prediction below, whose own loads they would otherwise wait behind)
     // approximate sum of everything before this group: from the scan kernel, or (few groups) summed here
     double before[2] = {0.0, 0.0};
 #pragma unroll
@@ -449,21 +464,6 @@ __device__ __forceinline__ void xs_summarize_body(xsm_shared<(KIND == XS_BOTH_SA
         start[wave][lane] = (wave ? before[1] : before[0]) + (incl - v);
     }
     __syncthreads();
-    const int sub = threadIdx.x & 15;  // position inside the cell's 16 lanes
-    const int pass_lo = flat ? (int)(bid & 3) : 0, pass_hi = flat ? pass_lo + 1 : 4;
-    // Loads are coalesced -- load j of a lane fetches elements 32 j + 2 sub, + 1 of its cell, so 16 lanes read 256
-    // contiguous bytes (8 consecutive elements per lane, the layout the scan wants, made every load touch 64 different
-    // lines: 3.8 TB/s at best) -- and the terms go through LDS to reach the lane that scans them: lane r of the cell owns
-    // elements 8 r .. 8 r + 7, rows of 10 doubles keep the 16-byte accesses conflict-free.  The next pass's loads are
-    // issued before this pass is worked on.
-    double *const mine = tr[0][wave] + (threadIdx.x & 48) * 10;  // this cell's 16 rows (slot 0)
-    double2       u[4], v[4];
-    auto fetch = [&](int pass) {
-        const int64_t cell = g * XS_GROUP + pass * 16 + (threadIdx.x >> 4);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) xs_raw<KIND>(cell < ncells ? n : 0, a, b, c, cell * XS_CELL + 32 * j + 2 * sub, u[j], v[j]);
-    };
-    fetch(pass_lo);
 #pragma unroll 1
     for (int pass = pass_lo; pass < pass_hi; ++pass) {
         const int     ci = pass * 16 + (threadIdx.x >> 4);
