@@ -66,7 +66,7 @@ def lib():
     L.cgh_config_sell_sigma.argtypes = [C.c_int]
     L.cgh_csrb_plan_host.argtypes = [i64, ip, C.c_int, ip, ip]
     L.cgh_csrb_plan_host.restype = i64
-    L.cgh_config_pb.argtypes = [C.c_int, i64, C.c_int]
+    L.cgh_config_pb.argtypes = [C.c_int, i64, C.c_int, C.c_int]
     L.cgh_pb_partition_host.argtypes = [i64, C.POINTER(C.c_int64), C.c_int, i64, C.POINTER(C.c_int64)]
     L.cgh_pb_partition_host.restype = i64
     L.cgh_matrix_free.argtypes = [vp]
@@ -171,9 +171,9 @@ def config_sell_sigma(sigma):
     check(lib().cgh_config_sell_sigma(sigma), "cgh_config_sell_sigma")
 
 
-def config_pb(span_bits=0, target_entries=0, split=0):
+def config_pb(span_bits=0, target_entries=0, split=0, ordered=-1):
     """tuning of the two-phase (propagation-blocking) matrices constructed after the call (cgh_config_pb in include/cg_hip.h)"""
-    check(lib().cgh_config_pb(span_bits, target_entries, split), "cgh_config_pb")
+    check(lib().cgh_config_pb(span_bits, target_entries, split, ordered), "cgh_config_pb")
 
 
 def pb_partition(cum, max_groups, target):

@@ -94,6 +94,7 @@ struct cgh_matrix {
     // by (row block, column block) with 2-byte local columns / rows; pb_prod is the launch's product stream (workspace of the
     // matrix: launches on one matrix must not overlap)
     int             pb_blocks = 0, pb_span = 0, pb_split = 1;
+    bool            pb_ordered = false;  // phase 2 adds the stream's pieces in stream order (same bits on every run)
     int            *pb_bnd = nullptr;   // [pb_blocks + 1] first row of each block
     int            *pb_pre = nullptr;   // [pb_blocks][pb_blocks + 1] per column block: flat position of each of its segments
     unsigned       *pb_seg0 = nullptr;  // [pb_blocks][pb_blocks] per column block: array position of each of its segments
@@ -136,6 +137,7 @@ struct cgh_config {
     int pb_span_bits = 14;      // CGH_PB_SPAN_BITS: log2 of the most rows a block of the two-phase layout holds (13 | 14)
     int64_t pb_target_entries = 131072; // CGH_PB_TARGET: entries per block the partition aims at
     int pb_split = 1;           // CGH_PB_SPLIT: workgroups sharing one column block in phase 1
+    int pb_ordered = 0;         // CGH_PB_ORDERED: 1 = phase 2 adds in stream order (same bits on every run, +14 % time); 0 = as the LDS atomics retire
 };
 extern cgh_config g_cfg;
 

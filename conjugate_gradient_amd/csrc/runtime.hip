@@ -45,6 +45,7 @@ static void read_env_knobs()
     g_cfg.pb_span_bits = env_int("CGH_PB_SPAN_BITS", g_cfg.pb_span_bits);
     if (getenv("CGH_PB_TARGET")) g_cfg.pb_target_entries = atoll(getenv("CGH_PB_TARGET"));
     g_cfg.pb_split = env_int("CGH_PB_SPLIT", g_cfg.pb_split);
+    g_cfg.pb_ordered = env_int("CGH_PB_ORDERED", g_cfg.pb_ordered);
 }
 
 extern "C" {

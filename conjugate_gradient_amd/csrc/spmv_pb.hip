@@ -22,7 +22,8 @@
 // Bytes per entry: 10 read + 8 written in phase 1, 10 read in phase 2 = 28 against the 12 algorithmic ones; no access
 // to HBM or L2 is random.  Throughput layout only: a row's products are added in the order the LDS atomics retire
 // (not the reference's order, and not the same from run to run: results agree with the exact-order kernels to a few
-// ulps of the row's magnitude); strict solves and exact_rows callers keep CGH_LAYOUT_CSR / ELL.
+// ulps of the row's magnitude) -- or, ORDERED (cgh_config_pb / CGH_PB_ORDERED=1), in the order of the product stream:
+// the same bits on every run, for 14 % more time.  Strict solves and exact_rows callers keep CGH_LAYOUT_CSR / ELL.
 #include <algorithm>
 #include <vector>
 
@@ -211,7 +212,12 @@ __global__ __launch_bounds__(SPAN / 16) void pb_expand(int B, int split, const i
 }
 
 // pb_accumulate.  One workgroup per row block: row sums in LDS, products streamed from the block's one contiguous run.
-template <int SPAN, bool DOT>
+// ORDERED: the waves add their pieces of the stream in the stream's order -- a wave issues its LDS atomics only once the
+// ticket names its piece, and hands the ticket on behind them (LDS executes a CU's instructions in arrival order, so whoever
+// reads the new ticket is behind those adds; lanes of one instruction that meet on a row are applied in lane order).  The
+// order of additions into a row is then fixed by the layout: same bits on every run.  The loads of a piece are in flight
+// while its wave waits for its turn.
+template <int SPAN, bool DOT, bool ORDERED>
 __global__ __launch_bounds__(SPAN / 16) void pb_accumulate(int B, const int *__restrict__ bnd, const int64_t *__restrict__ bin_ptr,
                                                           const double *__restrict__ prod, const unsigned short *__restrict__ lrow,
                                                           const double *__restrict__ diag, const double *__restrict__ x,
@@ -221,18 +227,24 @@ __global__ __launch_bounds__(SPAN / 16) void pb_accumulate(int B, const int *__r
     constexpr int T = SPAN / 16, NW = T / 64;
     __shared__ double acc[SPAN];
     __shared__ double red[NW];
+    __shared__ int    ticket;
     if (done != nullptr && *done != 0) return;
     const int b = B - 1 - (int)blockIdx.x;
     const int r0 = bnd[b], cnt = bnd[b + 1] - r0;
     for (int i = threadIdx.x; i < cnt; i += T) acc[i] = 0.0;
+    if (threadIdx.x == 0) ticket = 0;
     __syncthreads();
-    const int64_t k1 = bin_ptr[b + 1];  // both ends are multiples of PAD
-    for (int64_t k = bin_ptr[b] + 2 * threadIdx.x; k < k1; k += 8 * T) {
-        d2_t     p[4];
-        unsigned r[4];
+    const int64_t k0 = bin_ptr[b], k1 = bin_ptr[b + 1];  // both ends are multiples of PAD
+    const int     wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    // a piece = UN x 128 consecutive entries of ONE wave (ORDERED) / UN x 2 T entries of the workgroup, lane pairs interleaved
+    constexpr int UN = ORDERED ? 8 : 4;
+    const int64_t pieces = ORDERED ? (k1 - k0 + UN * 128 - 1) / (UN * 128) : (k1 - k0 + 2 * UN * T - 1) / (2 * UN * T);
+    for (int64_t pc = ORDERED ? wave : 0; pc < pieces; pc += ORDERED ? NW : 1) {
+        d2_t     p[UN];
+        unsigned r[UN];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int64_t kq = k + q * 2 * T;
+        for (int q = 0; q < UN; ++q) {
+            const int64_t kq = ORDERED ? k0 + pc * (UN * 128) + q * 128 + 2 * lane : k0 + pc * 2 * UN * T + q * 2 * T + 2 * threadIdx.x;
             p[q] = d2_t{0.0, 0.0};
             r[q] = 0xffffffffu;
             if (kq < k1) {
@@ -240,10 +252,17 @@ __global__ __launch_bounds__(SPAN / 16) void pb_accumulate(int B, const int *__r
                 r[q] = __builtin_nontemporal_load((const unsigned *)(lrow + kq));
             }
         }
+        if constexpr (ORDERED) {
+            while (__hip_atomic_load(&ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != (int)pc) {
+            }
+        }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < UN; ++q) {
             if ((r[q] & 0xffffu) != 0xffffu) unsafeAtomicAdd(&acc[r[q] & 0xffffu], p[q].x);
             if ((r[q] >> 16) != 0xffffu) unsafeAtomicAdd(&acc[r[q] >> 16], p[q].y);
+        }
+        if constexpr (ORDERED) {
+            if (lane == 0) __hip_atomic_store(&ticket, (int)pc + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
     }
     __syncthreads();
@@ -272,12 +291,14 @@ void launch(const cgh_matrix *m, const double *x, double *y, double *dot_partial
     const int B = m->pb_blocks, split = m->pb_split > 0 ? m->pb_split : 1;
     hipLaunchKernelGGL((pb_expand<SPAN>), dim3(B * split), dim3(SPAN / 16), 0, s, B, split, (const int *)m->pb_bnd, (const int *)m->pb_pre,
                        (const unsigned *)m->pb_seg0, (const double *)m->vals, (const unsigned short *)m->pb_lcol, x, m->pb_prod, done);
-    if (dot_partials)
-        hipLaunchKernelGGL((pb_accumulate<SPAN, true>), dim3(B), dim3(SPAN / 16), 0, s, B, (const int *)m->pb_bnd, (const int64_t *)m->pb_bin,
-                           (const double *)m->pb_prod, (const unsigned short *)m->pb_lrow, (const double *)m->diag, x, y, dot_partials, done);
-    else
-        hipLaunchKernelGGL((pb_accumulate<SPAN, false>), dim3(B), dim3(SPAN / 16), 0, s, B, (const int *)m->pb_bnd, (const int64_t *)m->pb_bin,
-                           (const double *)m->pb_prod, (const unsigned short *)m->pb_lrow, (const double *)m->diag, x, y, dot_partials, done);
+#define PB_ACC(D, O)                                                                                                                \
+    hipLaunchKernelGGL((pb_accumulate<SPAN, D, O>), dim3(B), dim3(SPAN / 16), 0, s, B, (const int *)m->pb_bnd, (const int64_t *)m->pb_bin, \
+                       (const double *)m->pb_prod, (const unsigned short *)m->pb_lrow, (const double *)m->diag, x, y, dot_partials, done)
+    if (dot_partials && m->pb_ordered) PB_ACC(true, true);
+    else if (dot_partials) PB_ACC(true, false);
+    else if (m->pb_ordered) PB_ACC(false, true);
+    else PB_ACC(false, false);
+#undef PB_ACC
 }
 
 } // namespace
@@ -329,6 +350,7 @@ cgh_matrix *cgh_pb_from_csr(cgh_matrix *csr)
     m->stored = nnz;
     m->pb_span = span;
     m->pb_split = g_cfg.pb_split > 0 ? g_cfg.pb_split : 1;
+    m->pb_ordered = g_cfg.pb_ordered != 0;
     bool ok = true;
     // 1. the partition (host, from the row pointer sampled every 256 rows)
     std::vector<int64_t> cum((size_t)(G + 1)), bg((size_t)(G + 1));
@@ -433,12 +455,14 @@ cgh_matrix *cgh_pb_from_csr(cgh_matrix *csr)
     return m;
 }
 
-extern "C" int cgh_config_pb(int span_bits, int64_t target_entries, int split)
+extern "C" int cgh_config_pb(int span_bits, int64_t target_entries, int split, int ordered)
 {
-    if ((span_bits != 0 && span_bits != 13 && span_bits != 14) || target_entries < 0 || split < 0 || split > 16) {
-        cgh_set_error("cgh_config_pb: rows per block 2^13 | 2^14 (0 = keep), entries per block >= 0 (0 = keep), workgroups per column block 0..16");
+    if ((span_bits != 0 && span_bits != 13 && span_bits != 14) || target_entries < 0 || split < 0 || split > 16 || ordered > 1) {
+        cgh_set_error("cgh_config_pb: rows per block 2^13 | 2^14 (0 = keep), entries per block >= 0 (0 = keep), workgroups per column block 0..16, "
+                      "ordered 0 | 1 (< 0 = keep)");
         return CGH_EINVAL;
     }
+    if (ordered >= 0) g_cfg.pb_ordered = ordered;
     if (span_bits) g_cfg.pb_span_bits = span_bits;
     if (target_entries) g_cfg.pb_target_entries = target_entries;
     if (split) g_cfg.pb_split = split;

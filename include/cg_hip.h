@@ -72,7 +72,8 @@ enum {
     CGH_LAYOUT_PB = 5     /* two-phase SpMV (propagation blocking; throughput layout for scattered columns, BASELINE config 5):
                              entries sorted by (row block, column block) with 2-byte local indices; phase 1 multiplies by x
                              staged in LDS and streams the products, phase 2 adds them into row sums held in LDS -- no random
-                             access leaves the CU; a row's sum is added in no fixed order (agrees to rounding, not bit for bit) */
+                             access leaves the CU; a row's sum is added in no fixed order unless cgh_config_pb asks for one (agrees with the
+                             reference to rounding, not bit for bit) */
 };
 
 /* Host slot-major full ELL (what coo_to_ell_symmetric_full_colmajor produced) -> device. */
@@ -109,8 +110,10 @@ int     cgh_matrix_set_exact_rows(cgh_matrix *m, int exact);
 int     cgh_config_csrb(int rows_per_wave_block, int slab_bits, int wgs_per_cu, int window, int quorum_div, int lds_atomics);
 int     cgh_config_sell_sigma(int sigma_rows);
 /* Tuning of the CGH_LAYOUT_PB matrices constructed after the call (0 keeps): log2 of the most rows per block (13 | 14), entries
- * per block the partition aims at, workgroups sharing one column block in phase 1 (1..16). */
-int     cgh_config_pb(int span_bits, int64_t target_entries, int split);
+ * per block the partition aims at, workgroups sharing one column block in phase 1 (1..16); ordered: 1 = phase 2 adds the
+ * products in the order of the stream (the same bits on every run, about 14 % slower), 0 = as the LDS atomics retire (the
+ * default), < 0 keeps. */
+int     cgh_config_pb(int span_bits, int64_t target_entries, int split, int ordered);
 /* Host-side partition of the two-phase layout (no GPU needed; exported for tests): cuts G groups of 256 rows (cum[g] =
  * entries before group g, cum[G] = all) into consecutive blocks of at most max_groups groups and, where that leaves a
  * choice, at most `target` entries.  bnd_g[0..B] receives the boundaries in groups.  Returns B. */

@@ -27,7 +27,7 @@ def cga():
     import conjugate_gradient_amd as m
     m.init(0)
     yield m
-    m.config_pb(14, 131072, 1)
+    m.config_pb(14, 131072, 1, 0)
 
 
 def _abs_bound(n, diag, vals, rows, cols, x):
@@ -98,6 +98,32 @@ def test_pb_pads_do_not_leak_non_finite_x(cga):
         touched[s["cols"][s["rows"] == bad]] = True
         touched[s["rows"][s["cols"] == bad]] = True
     assert np.all(np.isfinite(got[~touched])) and not np.any(np.isfinite(got[touched]))
+
+
+@pytest.mark.parametrize("cfg", PB_CONFIGS)
+def test_pb_ordered_mode_gives_the_same_bits_every_run(cga, cfg):
+    """cgh_config_pb(..., ordered=1): phase 2 adds the product stream's pieces in stream order -- SpMV output and a whole
+    CG trajectory bit-identical from run to run (the default order, as the LDS atomics retire, is not), same accuracy"""
+    cga.config_pb(*cfg, 1)
+    n, max_len, seed = 40001, 500, 0x5EED0005
+    s = foamio.powerlaw_coo(n, max_len, seed)
+    rng = np.random.default_rng(4)
+    diag = 1.0 + np.bincount(s["rows"], np.abs(s["upper"]), n) + np.bincount(s["cols"], np.abs(s["upper"]), n)
+    xh = rng.standard_normal(n)
+    A = cga.Matrix.from_coo(n, diag, s["upper"], s["rows"], s["cols"], cga.LAYOUT_PB)
+    x = cga.DeviceVector.from_host(xh); y = cga.DeviceVector(n)
+    A.spmv(x, y)
+    first = y.to_host()
+    want = O.mv_coo(n, diag, s["upper"], s["rows"], s["cols"], xh)
+    assert np.all(np.abs(first - want) <= 16 * np.finfo(float).eps * _abs_bound(n, diag, s["upper"], s["rows"], s["cols"], xh))
+    for _ in range(6):
+        A.spmv(x, y)
+        assert np.array_equal(y.to_host().view(np.uint64), first.view(np.uint64))
+    b = cga.DeviceVector.from_host(rng.standard_normal(n)); xs = cga.DeviceVector(n)
+    rep, hist = cga.cg_solve(A, b, xs, max_iter=60, tol=1e-9, strict=0)
+    rep2, hist2 = cga.cg_solve(A, b, xs, max_iter=60, tol=1e-9, strict=0)
+    assert rep2.ret == rep.ret and hist.tobytes() == hist2.tobytes()
+    cga.config_pb(0, 0, 0, 0)
 
 
 @pytest.mark.parametrize("tag", ["cylinder_2000", "poisson7_32x24x20", "poisson27_12x10x8"])

@@ -46,9 +46,13 @@ def compare(n, max_len, cfgs, time_csr=True):
         A.spmv(x, y)
         got = y.to_host()
         err = np.abs(got - ref).max() / scale
+        same = 0
+        for _ in range(5):
+            A.spmv(x, y)
+            same += int(np.array_equal(y.to_host().view(np.uint64), got.view(np.uint64)))
         t = spmv_time(A, x, y)
-        print("  PB span_bits=%d target=%d split=%d build %.2fs bytes %.3fx CSR  max err %.2e  spmv %.4f ms  %.2f TB/s alg (%.1f%% of 8)" % (
-            span_bits, target, split, tb, A.stored_bytes / csr_bytes, err, t, alg / t / 1e9, alg / t / 8e7), flush=True)
+        print("  PB span_bits=%d target=%d split=%d build %.2fs bytes %.3fx CSR  max err %.2e  same bits in %d of 5 reruns  spmv %.4f ms  %.2f TB/s alg (%.1f%% of 8)" % (
+            span_bits, target, split, tb, A.stored_bytes / csr_bytes, err, same, t, alg / t / 1e9, alg / t / 8e7), flush=True)
         assert err < 1e-13, err
         A.free()
 
