@@ -1059,16 +1059,29 @@ __global__ __launch_bounds__(XD_THREADS) void xs_drive(int64_t n, const double *
 // should a count never fill up (it cannot, short of a fault elsewhere) every wait gives up after ~2 s and the sums are NaN.
 constexpr long long XR_PATIENCE = 200000000;  // ticks of the 100 MHz clock
 
+constexpr int XR_CHAINS = 20;  // cells whose elements are fetched ahead of the walk (few cells only)
+
 struct xr_shared {
     double stage[XS_CELL];
+    double chain[XR_CHAINS][XS_CELL];
+    int    chain_cell[XR_CHAINS];  // the cell whose elements chain[k] holds, -1 until they are in
+    int    chain_n, walked, abort;
 };
+
+__device__ __forceinline__ int xr_peek(const int *p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void xr_post(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
 template <int KIND>
 __device__ __forceinline__ double xr_chain(xr_shared &S, double s, int slot, int64_t n, const double *__restrict__ a,
                                            const double *__restrict__ b, const double *__restrict__ c, int64_t cell)
 {
     const int lane = threadIdx.x & 63;
-    double    t0, t1;
+    {   // fetched ahead?
+        const int                have = xr_peek(&S.chain_n) < XR_CHAINS ? xr_peek(&S.chain_n) : XR_CHAINS;
+        const unsigned long long hit = __ballot(lane < have && xr_peek(&S.chain_cell[lane < XR_CHAINS ? lane : 0]) == (int)cell);
+        if (hit) return xs_chain(s, S.chain[__builtin_ctzll(hit)]);
+    }
+    double t0, t1;
     xs_cell_terms<KIND>(slot, n, a, b, c, cell, t0, t1);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();  // the previous cell's reads are over
@@ -1077,6 +1090,50 @@ __device__ __forceinline__ double xr_chain(xr_shared &S, double s, int slot, int
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     return xs_chain(s, S.stage);
+}
+
+// Few cells: the launch is short and the walk's descents are its critical path, each a round trip to memory.  Waves 1..3 of
+// the driver run ahead of the walk: wave w takes the batches w-1, w+2, ... as their flags go up, looks for cells flagged
+// irregular (to be added element by element) and fetches their elements into LDS.  Best effort: the walk fetches what it
+// does not find.
+template <int KIND>
+__device__ void xr_fetch_ahead(xr_shared &S, int slot, int64_t n, const double *__restrict__ a, const double *__restrict__ b,
+                               const double *__restrict__ c, int64_t ncells, int nb, const xs_summary *__restrict__ cells,
+                               const unsigned *__restrict__ ready)
+{
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    cells += slot * ncells;
+    for (int bb = w - 1; bb < nb; bb += 3) {
+        const long long t0 = wall_clock64();
+        for (;;) {
+            if (xr_peek(&S.walked) > bb || xr_peek(&S.abort) || wall_clock64() - t0 > XR_PATIENCE) break;
+            unsigned f = 0;
+            if (lane == 0) f = __hip_atomic_load(ready + bb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((unsigned)__builtin_amdgcn_readfirstlane((int)f) >= XS_BATCH_READY) break;
+            __builtin_amdgcn_s_sleep(4);
+        }
+        if (xr_peek(&S.walked) > bb) continue;
+        if (xr_peek(&S.abort) || wall_clock64() - t0 > XR_PATIENCE) return;
+        const int64_t c0 = (int64_t)bb * XS_GROUP;
+        const int     ccnt = (int)(ncells - c0 < XS_GROUP ? ncells - c0 : XS_GROUP);
+        xs_summary    Cq = xs_identity();
+        if (lane < ccnt) Cq = xs_load_agent(cells + c0 + lane);
+        unsigned long long irr = __ballot((Cq.meta & XS_IRREGULAR) != 0);
+        while (irr) {
+            const int64_t cell = c0 + __builtin_ctzll(irr);
+            irr &= irr - 1;
+            int id = 0;
+            if (lane == 0) id = atomicAdd(&S.chain_n, 1);
+            id = __builtin_amdgcn_readfirstlane(id);
+            if (id >= XR_CHAINS) return;
+            double t0e, t1e;
+            xs_cell_terms<KIND>(slot, n, a, b, c, cell, t0e, t1e);
+            *reinterpret_cast<double2 *>(&S.chain[id][2 * lane]) = make_double2(t0e, t1e);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (lane == 0) xr_post(&S.chain_cell[id], (int)cell);
+        }
+    }
 }
 
 // the sum of slot `slot` while the summaries are still being built (one wave).  FLAT: no group level, a batch is 64 cells.
@@ -1108,7 +1165,10 @@ __device__ double xr_sum(xr_shared &S, int slot, int64_t n, const double *__rest
         const unsigned long long rdy = __ballot(f >= XS_BATCH_READY);
         const int                m = ~rdy ? (int)__builtin_ctzll(~rdy) : 64;
         if (m == 0) {
-            if (wall_clock64() - t0 > XR_PATIENCE) return NAN;
+            if (wall_clock64() - t0 > XR_PATIENCE) {
+                if (lane == 0) xr_post(&S.abort, 1);
+                return NAN;
+            }
             __builtin_amdgcn_s_sleep(8);
             continue;
         }
@@ -1165,6 +1225,7 @@ __device__ double xr_sum(xr_shared &S, int slot, int64_t n, const double *__rest
             tstart = fb + 1;
         }
         cur += m;
+        if (lane == 0) xr_post(&S.walked, cur);
         XR_STAMP(152, cur - 1);
         t0 = wall_clock64();
     }
@@ -1238,9 +1299,17 @@ __global__ __launch_bounds__(256) void xs_fused(int64_t n, const double *__restr
                                              cells, groups, nullptr, ready, batches, nbatch);
         return;
     }
-    if (threadIdx.x >= 64) return;  // a driver is one wave
-    const int    slot = S0 + (int)blockIdx.x;
-    const double s = xr_sum<KIND, FLAT>(*reinterpret_cast<xr_shared *>(raw), slot, n, a, b, c, ncells, ngroups, cells, groups,
+    const int  slot = S0 + (int)blockIdx.x;
+    xr_shared &S = *reinterpret_cast<xr_shared *>(raw);
+    if (threadIdx.x < XR_CHAINS) S.chain_cell[threadIdx.x] = -1;
+    if (threadIdx.x == 0) S.chain_n = S.walked = S.abort = 0;
+    __syncthreads();
+    if (threadIdx.x >= 64) {  // the walk is one wave; with few cells the others fetch ahead of it
+        if constexpr (FLAT)
+            xr_fetch_ahead<KIND>(S, slot, n, a, b, c, ncells, (int)nbatch, cells, ready + (slot - S0) * nbatch);
+        return;
+    }
+    const double s = xr_sum<KIND, FLAT>(S, slot, n, a, b, c, ncells, ngroups, cells, groups,
                                   batches + (slot - S0) * nbatch, ready + (slot - S0) * nbatch, slot == S0 ? trace : nullptr);
     if (threadIdx.x != 0) return;
     double s_dot = s, s_l1 = s;
