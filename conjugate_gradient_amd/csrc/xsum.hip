@@ -371,7 +371,8 @@ __device__ __forceinline__ xs_summary xs_load_agent(const xs_summary *src)
     return q;
 }
 static_assert(sizeof(xs_summary) == 40, "xs_summary is read and written as five 64-bit words");
-constexpr unsigned XS_BATCH_READY = 1u << 16;  // added to a batch's count of summarised groups once its own summary is in memory
+constexpr unsigned XS_BATCH_READY = 1u << 16;
+constexpr int      XS_DIRECT_BATCHES = 6;  // few cells, up to this many batches: nobody joins them, the walk takes their cells as they are counted  // added to a batch's count of summarised groups once its own summary is in memory
 // word `k` (0..4, one per lane) of lane 0's summary
 __device__ __forceinline__ unsigned long long readlane_words(const xs_summary &q, int k)
 {
@@ -579,7 +580,7 @@ __device__ __forceinline__ void xs_summarize_body(xsm_shared<(KIND == XS_BOTH_SA
             }
         }
         __syncthreads();
-        if (wave >= S0 && wave <= S1 && last[wave]) {
+        if (nbatch > XS_DIRECT_BATCHES && wave >= S0 && wave <= S1 && last[wave]) {
             const int  gc = (int)(ncells - g * XS_GROUP < XS_GROUP ? ncells - g * XS_GROUP : XS_GROUP);
             xs_summary q = xs_identity();
             if (lane < gc) q = xs_load_agent(cells + wave * ncells + g * XS_GROUP + lane);
@@ -1101,7 +1102,8 @@ __device__ void xr_fetch_ahead(xr_shared &S, int slot, int64_t n, const double *
                                const double *__restrict__ c, int64_t ncells, int nb, const xs_summary *__restrict__ cells,
                                const unsigned *__restrict__ ready)
 {
-    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int      lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const unsigned ready_at = nb <= XS_DIRECT_BATCHES ? 4u : XS_BATCH_READY;
     cells += slot * ncells;
     for (int bb = w - 1; bb < nb; bb += 3) {
         const long long t0 = wall_clock64();
@@ -1109,7 +1111,7 @@ __device__ void xr_fetch_ahead(xr_shared &S, int slot, int64_t n, const double *
             if (xr_peek(&S.walked) > bb || xr_peek(&S.abort) || wall_clock64() - t0 > XR_PATIENCE) break;
             unsigned f = 0;
             if (lane == 0) f = __hip_atomic_load(ready + bb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if ((unsigned)__builtin_amdgcn_readfirstlane((int)f) >= XS_BATCH_READY) break;
+            if ((unsigned)__builtin_amdgcn_readfirstlane((int)f) >= ready_at) break;
             __builtin_amdgcn_s_sleep(4);
         }
         if (xr_peek(&S.walked) > bb) continue;
@@ -1154,15 +1156,18 @@ __device__ double xr_sum(xr_shared &S, int slot, int64_t n, const double *__rest
     cells += slot * ncells;
     if (!FLAT) groups += slot * ngroups;
     const int nb = FLAT ? (int)ngroups : (int)((ngroups + 63) / 64);
-    double    s = 0.0;
-    int       cur = 0;
+    // few cells and few batches: a batch is ready as soon as its four workgroups are counted, and is walked cell by cell
+    const bool     direct = FLAT && nb <= XS_DIRECT_BATCHES;
+    const unsigned ready_at = direct ? 4u : XS_BATCH_READY;
+    double         s = 0.0;
+    int            cur = 0;
     long long t0 = wall_clock64();
     while (cur < nb) {
         // the batches from `cur` on whose summaries are in memory: a prefix of up to 64, taken together
         const int cnt = nb - cur < 64 ? nb - cur : 64;
         unsigned  f = 0;
         if (lane < cnt) f = __hip_atomic_load(ready + cur + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned long long rdy = __ballot(f >= XS_BATCH_READY);
+        const unsigned long long rdy = __ballot(f >= ready_at);
         const int                m = ~rdy ? (int)__builtin_ctzll(~rdy) : 64;
         if (m == 0) {
             if (wall_clock64() - t0 > XR_PATIENCE) {
@@ -1174,7 +1179,8 @@ __device__ double xr_sum(xr_shared &S, int slot, int64_t n, const double *__rest
         }
         xs_summary Bq = xs_identity();
         if (lane < m) {
-            Bq = xs_load_agent(batches + cur + lane);
+            if (direct) Bq = xs_regular(0, 0, 0, 0, 0, true);  // "does not apply": every batch is entered
+            else Bq = xs_load_agent(batches + cur + lane);
             __hip_atomic_store(ready + cur + lane, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // zero for the next launch
         }
         for (int q = 0; q < m; ++q) XR_STAMP(8, cur + q);
