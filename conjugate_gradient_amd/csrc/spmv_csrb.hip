@@ -22,6 +22,7 @@
 //     this is a throughput layout; parity callers use CGH_LAYOUT_CSR with exact rows.
 #include <algorithm>
 #include <queue>
+#include <exception>
 #include <vector>
 
 #include <cstring>
@@ -486,7 +487,7 @@ extern "C" int64_t cgh_csrb_plan_host(int64_t nseg, const int *weights, int spb,
 }
 
 // CSR (full rows, device) -> CSRB.  `csr` is consumed: its diag is adopted, its arrays are freed.
-cgh_matrix *cgh_csrb_from_csr(cgh_matrix *csr)
+static cgh_matrix *cgh_csrb_from_csr_impl(cgh_matrix *csr)
 {
     hipStream_t   s = g_cgh.stream;
     const int64_t n = csr->n, nnz = csr->nnz_off;
@@ -584,6 +585,17 @@ cgh_matrix *cgh_csrb_from_csr(cgh_matrix *csr)
         return nullptr;
     }
     return m;
+}
+
+// (host containers inside: nothing may leave through the extern "C" callers as an exception)
+cgh_matrix *cgh_csrb_from_csr(cgh_matrix *csr)
+{
+    try {
+        return cgh_csrb_from_csr_impl(csr);
+    } catch (const std::exception &e) {
+        cgh_set_error("column-blocked CSR: %s", e.what());
+        return nullptr;  // (csr may be lost with it: the process is out of host memory)
+    }
 }
 
 // diagnostic build of the kernel (rows per wave-block 1024, no dot): block b writes the 100 MHz clock at which it enters

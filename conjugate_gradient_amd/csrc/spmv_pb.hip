@@ -25,6 +25,7 @@
 // ulps of the row's magnitude) -- or, ORDERED (cgh_config_pb / CGH_PB_ORDERED=1), in the order of the product stream:
 // the same bits on every run, for 14 % more time.  Strict solves and exact_rows callers keep CGH_LAYOUT_CSR / ELL.
 #include <algorithm>
+#include <exception>
 #include <vector>
 
 #include <rocprim/device/device_radix_sort.hpp>
@@ -330,7 +331,7 @@ extern "C" int64_t cgh_pb_partition_host(int64_t G, const int64_t *cum, int max_
 }
 
 // CSR (full rows, device) -> PB.  `csr` is consumed: its diag is adopted, its arrays are freed.
-cgh_matrix *cgh_pb_from_csr(cgh_matrix *csr)
+static cgh_matrix *cgh_pb_from_csr_impl(cgh_matrix *csr)
 {
     hipStream_t   s = g_cgh.stream;
     const int64_t n = csr->n, nnz = csr->nnz_off;
@@ -453,6 +454,17 @@ cgh_matrix *cgh_pb_from_csr(cgh_matrix *csr)
         return nullptr;
     }
     return m;
+}
+
+// (host containers inside: nothing may leave through the extern "C" callers as an exception)
+cgh_matrix *cgh_pb_from_csr(cgh_matrix *csr)
+{
+    try {
+        return cgh_pb_from_csr_impl(csr);
+    } catch (const std::exception &e) {
+        cgh_set_error("two-phase SpMV layout: %s", e.what());
+        return nullptr;  // (csr may be lost with it: the process is out of host memory)
+    }
 }
 
 extern "C" int cgh_config_pb(int span_bits, int64_t target_entries, int split, int ordered)
