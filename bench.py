@@ -355,6 +355,7 @@ def main():
             cga.check(cga.lib().cgh_time_spmv(M.h, b.ptr, y.ptr, 10, C.byref(ms)))
             if layout == cga.LAYOUT_CSR:
                 csr_bytes = M.stored_bytes
+                out["config"]["row_length_offdiag_min_mean_max"] = [int(cga.lib().cgh_matrix_min_row(M.h)), M.nnz_offdiag / n, int(M.K)]
             lay[name] = {"stored_bytes": int(M.stored_bytes), "bytes_vs_csr": M.stored_bytes / csr_bytes, "spmv_ms": ms.value,
                          "spmv_GBs_algorithmic": alg_spmv / ms.value / 1e6, "frac": alg_spmv / ms.value / 1e6 / HBM_PEAK_GBS}
             if layout == cga.LAYOUT_CSR and not args.no_cpu_baseline:
