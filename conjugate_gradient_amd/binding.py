@@ -138,6 +138,8 @@ def lib():
         getattr(L, f).restype = i64
     L.cgh_dist_width.argtypes = [vp]
     L.cgh_dist_download_local.argtypes = [vp, dp, dp, ip]
+    L.cgh_dist_vector.argtypes = [vp, C.c_int]
+    L.cgh_dist_vector.restype = vp
     L.cgh_dist_start.argtypes = [vp, vp, vp, C.c_double, C.c_int]
     L.cgh_dist_set_strict.argtypes = [vp, C.c_int]
     L.cgh_dist_iterate.argtypes = [vp, C.c_int, C.c_int]
@@ -149,10 +151,14 @@ def lib():
     L.cgh_dist_group_iterate.argtypes = [vpp, C.c_int, C.c_int]
     L.cgh_time_spmv.argtypes = [vp, vp, vp, C.c_int, dp]
     L.cgh_time_copy.argtypes = [vp, vp, C.c_size_t, C.c_int, dp]
+    L.cgh_time_copy_variant.argtypes = [vp, vp, C.c_size_t, C.c_int, C.c_int, dp]
     L.cgh_time_read.argtypes = [vp, vp, C.c_size_t, C.c_int, dp]
     L.cgh_time_read_8_4.argtypes = [vp, vp, vp, C.c_size_t, C.c_int, dp]
     L.cgh_xsum_set_prof.argtypes = [vp]
     L.cgh_xsum_set_prof.restype = None
+    L.cgh_alloc_calls.restype = C.c_longlong
+    L.cgh_mem_info.argtypes = [C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+    L.cgh_capture_end_launch.argtypes = [C.c_int]
     _lib = L
     return L
 
@@ -447,6 +453,15 @@ class DistRank:
         d = np.empty(self.n_loc); ev = np.empty(self.n_loc * self.K); ec = np.empty(self.n_loc * self.K, dtype=np.int32)
         check(lib().cgh_dist_download_local(self.h, _D(d), _D(ev), _I(ec)), "dist_download_local")
         return d, ev, ec
+
+    def vector_to_host(self, which):
+        """r (0), p (1) or A p (2) of the solve in flight: the owned rows, copied to the host"""
+        out = np.empty(self.n_loc)
+        ptr = lib().cgh_dist_vector(self.h, which)
+        if not ptr:
+            raise RuntimeError("cgh_dist_vector: no solve in flight")
+        check(lib().cgh_d2h(out.ctypes.data, ptr, out.nbytes), "d2h")
+        return out
 
     def loopback(self):
         """one-GPU timing harness: this inner slab becomes its own two neighbours (cgh_dist_loopback)"""

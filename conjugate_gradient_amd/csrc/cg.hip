@@ -586,11 +586,14 @@ int cgh_cg_solve(const cgh_matrix *m, const double *d_b, double *d_x, const cgh_
 // that pointer is handed to kernels and memsets.  Every call on a GPU shares that GPU's array and finds the previous
 // call's contents in it: what must start at zero (the converged flag) is cleared, everything else is written before
 // it is read.  Calls that overlap on one GPU (two host threads) would race on it.
-constexpr int64_t NOALLOC_MAX_ROWS = 1 << 20;  // 3 vectors of 2^20 doubles + partials: 25.2 MB per GPU, held until the process ends
+constexpr int64_t NOALLOC_MAX_ROWS = 1 << 20;  // 3 vectors of 2^20 doubles + partials + 1 MiB for the order-exact sums: 26.2 MB per GPU, held until the process ends
 constexpr size_t  NOALLOC_PART_A = (size_t)3 * NOALLOC_MAX_ROWS;
 constexpr size_t  NOALLOC_PART_B = NOALLOC_PART_A + CGH_MAX_PARTIALS;
 constexpr size_t  NOALLOC_DONE = NOALLOC_PART_B + 2 * CGH_MAX_PARTIALS;
-constexpr size_t  NOALLOC_DOUBLES = NOALLOC_DONE + 32;
+constexpr size_t  NOALLOC_XSUM = NOALLOC_DONE + 32;            // workspace of the order-exact sums (strict mode from 4096 rows on)
+constexpr size_t  NOALLOC_XSUM_DOUBLES = (size_t)1 << 17;      // 1 MiB; 2^20 rows need 803 840 bytes (cgh_xsum_device_bytes)
+constexpr size_t  NOALLOC_DOUBLES = NOALLOC_XSUM + NOALLOC_XSUM_DOUBLES;
+static_assert((NOALLOC_XSUM * sizeof(double)) % 256 == 0, "the sums' workspace starts on a 256-byte boundary");
 static __device__ __align__(256) double scratch[NOALLOC_DOUBLES];
 static double *g_scratch_ptr[64] = {nullptr};  // per device: each GPU holds its own copy of the array at its own address
 
@@ -612,14 +615,13 @@ extern "C" int cgh_cg_solve_noalloc(const cgh_matrix *m, const double *d_b, doub
         cgh_set_error("cgh_cg_solve_noalloc: NULL argument or max_iter < 1");
         return CGH_EINVAL;
     }
+    if (m->n <= 0) {
+        cgh_set_error("cgh_cg_solve_noalloc: the matrix has no rows");
+        return CGH_EINVAL;
+    }
     if (m->n > NOALLOC_MAX_ROWS) {
         cgh_set_error("cgh_cg_solve_noalloc: %lld rows exceed the %lld rows the built-in workspace holds (use cgh_cg_solve)",
                       (long long)m->n, (long long)NOALLOC_MAX_ROWS);
-        return CGH_EINVAL;
-    }
-    if (strict && m->n >= xsum_min_rows()) {
-        cgh_set_error("cgh_cg_solve_noalloc: strict sums of %lld or more rows need the order-exact workspace, which is allocated "
-                      "(use cgh_cg_solve, or strict = 0)", (long long)xsum_min_rows());
         return CGH_EINVAL;
     }
     double *ws = g_cgh.device >= 0 && g_cgh.device < 64 ? g_scratch_ptr[g_cgh.device] : nullptr;
@@ -628,6 +630,19 @@ extern "C" int cgh_cg_solve_noalloc(const cgh_matrix *m, const double *d_b, doub
         return CGH_ENODEV;
     }
     cgh_solver sv;  // on the stack; its vectors stay empty (no time_kernels, no graphs)
+    alignas(16) unsigned char xs_obj[256];  // descriptor of the order-exact sums' workspace, also on the stack
+    if (strict && m->n >= xsum_min_rows()) {
+        // bit-identical sums of a long vector: their workspace (summaries, counters) is the tail of the same array
+        if (cgh_xsum_object_bytes() > sizeof xs_obj || cgh_xsum_device_bytes(m->n) > NOALLOC_XSUM_DOUBLES * sizeof(double)) {
+            cgh_set_error("cgh_cg_solve_noalloc: the built-in workspace cannot hold the order-exact sums of %lld rows", (long long)m->n);
+            return CGH_EINVAL;
+        }
+        sv.xs = cgh_xsum_place(xs_obj, sizeof xs_obj, m->n, ws + NOALLOC_XSUM, NOALLOC_XSUM_DOUBLES * sizeof(double), g_cgh.stream);
+        if (!sv.xs) {
+            cgh_set_error("cgh_cg_solve_noalloc: could not lay out the order-exact sums' workspace");
+            return CGH_EHIP;
+        }
+    }
     sv.m = m;
     sv.n = m->n;
     sv.capacity = max_iter;

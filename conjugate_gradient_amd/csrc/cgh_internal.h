@@ -140,6 +140,10 @@ struct cgh_config {
     int pb_ordered = 0;         // CGH_PB_ORDERED: 1 = phase 2 adds in stream order (same bits on every run, +14 % time); 0 = as the LDS atomics retire
 };
 extern cgh_config g_cfg;
+// What a cgh_config_* setter writes: the field of g_cfg now, and again after every later cgh_init / cgh_config_reload
+// (which start from the defaults and the environment) -- until cgh_config_reset() forgets the setters' values.
+void cgh_config_set(int *field_of_g_cfg, int v);
+void cgh_config_set(int64_t *field_of_g_cfg, int64_t v);
 
 // ------------------------------------------------------------ launch shapes
 constexpr int CGH_BLOCK = 256;          // 4 waves of 64
@@ -183,6 +187,10 @@ int cgh_cg_solve_sink(const cgh_matrix *m, const double *d_b, double *d_x, const
 struct cgh_xsum;
 cgh_xsum *cgh_xsum_create(int64_t n);
 void      cgh_xsum_free(cgh_xsum *w);
+// the same workspace in memory of the caller's (no allocation at all): see xsum.hip
+size_t    cgh_xsum_object_bytes(void);
+size_t    cgh_xsum_device_bytes(int64_t n);
+cgh_xsum *cgh_xsum_place(void *obj, size_t obj_bytes, int64_t n, void *dev, size_t dev_bytes, hipStream_t s);
 // Same contract as the seq_sums kernel (cg_kernels.h): dot = sum a[i]*b[i] (a != NULL), l1 = sum |c[i]| (c != NULL), both
 // added strictly left to right; mode 0: out = {dot, l1}; 1: alpha; 2: res, rr, beta, done; 3: initial res, rr.
 // a, b, c must either be (a, b, NULL), (NULL, NULL, c) or (v, v, v).

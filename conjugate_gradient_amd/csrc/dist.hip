@@ -1000,6 +1000,12 @@ int cgh_dist_download_local(const cgh_dist *d, double *diag, double *ell_vals, i
     return cgh_d2h(ell_cols, d->mat.cols, sizeof(int) * (size_t)d->mat.stored);
 }
 int cgh_dist_width(const cgh_dist *d) { return d->mat.K; }
+// test/debug access to the vectors of the solve in flight (device pointers, owned rows first): 0 = r, 1 = p, 2 = A p
+const double *cgh_dist_vector(const cgh_dist *d, int which)
+{
+    if (!d) return nullptr;
+    return which == 0 ? d->r : which == 1 ? d->p : which == 2 ? d->Ap : nullptr;
+}
 int64_t cgh_dist_halo(const cgh_dist *d) { return d->n_halo; }
 
 // Bit-identical mode for the solves started from now on (every rank makes the same choice): trajectory, x and the

@@ -33,13 +33,40 @@ int cgh_launch_spmv(const cgh_matrix *m, const double *x, double *y, double *dot
 
 namespace {
 
-__global__ __launch_bounds__(256) void copy16(const uint4 *__restrict__ src, uint4 *__restrict__ dst, size_t count)
+typedef unsigned u4_t __attribute__((ext_vector_type(4)));
+
+// The device-to-device copy that serves as the attainable-HBM yardstick of the bench line: UN independent 16-byte loads
+// in flight per lane (a workgroup moves tiles of 256 x UN x 16 bytes, consecutive lanes on consecutive 16 bytes), loads
+// and stores non-temporal or not.  (Round 2's yardstick had ONE load in flight per lane and temporal stores: 4.84 TB/s,
+// 23 % below what the part does on a copy.)
+template <int UN, bool NTL, bool NTS>
+__global__ __launch_bounds__(256) void copy16(const u4_t *__restrict__ src, u4_t *__restrict__ dst, size_t count)
 {
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+    const size_t tile = (size_t)256 * UN, tiles = count / tile;
+    for (size_t t = blockIdx.x; t < tiles; t += gridDim.x) {
+        const size_t i = t * tile + threadIdx.x;
+        u4_t         v[UN];
+#pragma unroll
+        for (int q = 0; q < UN; ++q) v[q] = NTL ? __builtin_nontemporal_load(src + i + q * 256) : src[i + q * 256];
+#pragma unroll
+        for (int q = 0; q < UN; ++q) {
+            if (NTS) __builtin_nontemporal_store(v[q], dst + i + q * 256);
+            else dst[i + q * 256] = v[q];
+        }
+    }
+    for (size_t i = tiles * tile + (size_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (size_t)gridDim.x * 256) dst[i] = src[i];
 }
 
+struct timing_events {
+    hipEvent_t a = nullptr, b = nullptr;
+    ~timing_events()
+    {
+        if (a) (void)hipEventDestroy(a);
+        if (b) (void)hipEventDestroy(b);
+    }
+};
+
 // read-only stream: 4 independent 16-byte non-temporal loads in flight per lane, one word per workgroup written
-typedef unsigned u4_t __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256) void read16(const u4_t *__restrict__ src, unsigned *__restrict__ sink, size_t count)
 {
     unsigned     acc = 0;
@@ -79,21 +106,19 @@ int cgh_time_read_8_4(const void *d_src8, const void *d_src4, void *d_sink_8k, s
     CGH_REQUIRE_READY(CGH_ENODEV);
     if (reps < 1 || !d_src8 || !d_src4 || !d_sink_8k) return CGH_EINVAL;
     hipStream_t s = g_cgh.stream;
-    hipEvent_t  a, b;
-    CGH_HIP(hipEventCreate(&a));
-    CGH_HIP(hipEventCreate(&b));
-    const int grid = g_cgh.num_cu * 8;
-    if (grid > 2048) return CGH_EINVAL;
-    CGH_HIP(hipEventRecord(a, s));
+    const int   grid = g_cgh.num_cu * 8;
+    if (grid > 2048) return CGH_EINVAL;  // the sink holds 8 KiB
+    timing_events ev;                    // (destroyed on every way out)
+    CGH_HIP(hipEventCreate(&ev.a));
+    CGH_HIP(hipEventCreate(&ev.b));
+    CGH_HIP(hipEventRecord(ev.a, s));
     for (int k = 0; k < reps; ++k)
         hipLaunchKernelGGL(read8_4, dim3(grid), dim3(256), 0, s, (const unsigned long long *)d_src8, (const unsigned *)d_src4,
                            (unsigned *)d_sink_8k, count);
-    CGH_HIP(hipEventRecord(b, s));
+    CGH_HIP(hipEventRecord(ev.b, s));
     CGH_HIP(hipStreamSynchronize(s));
     float ms = 0.f;
-    CGH_HIP(hipEventElapsedTime(&ms, a, b));
-    (void)hipEventDestroy(a);
-    (void)hipEventDestroy(b);
+    CGH_HIP(hipEventElapsedTime(&ms, ev.a, ev.b));
     *ms_avg = (double)ms / reps;
     return CGH_OK;
 }
@@ -219,48 +244,76 @@ int cgh_time_spmv(const cgh_matrix *m, const double *d_x, double *d_y, int reps,
 {
     CGH_REQUIRE_READY(CGH_ENODEV);
     if (!m || reps < 1) return CGH_EINVAL;
-    hipStream_t s = g_cgh.stream;
-    hipEvent_t  a, b;
-    CGH_HIP(hipEventCreate(&a));
-    CGH_HIP(hipEventCreate(&b));
+    hipStream_t   s = g_cgh.stream;
+    timing_events ev;
+    CGH_HIP(hipEventCreate(&ev.a));
+    CGH_HIP(hipEventCreate(&ev.b));
     int rc = cgh_launch_spmv(m, d_x, d_y, nullptr, nullptr, nullptr, s);  // warm-up
     if (rc) return rc;
-    CGH_HIP(hipEventRecord(a, s));
+    CGH_HIP(hipEventRecord(ev.a, s));
     for (int k = 0; k < reps; ++k) {
         rc = cgh_launch_spmv(m, d_x, d_y, nullptr, nullptr, nullptr, s);
         if (rc) return rc;
     }
-    CGH_HIP(hipEventRecord(b, s));
+    CGH_HIP(hipEventRecord(ev.b, s));
     CGH_HIP(hipStreamSynchronize(s));
     float ms = 0.f;
-    CGH_HIP(hipEventElapsedTime(&ms, a, b));
-    (void)hipEventDestroy(a);
-    (void)hipEventDestroy(b);
+    CGH_HIP(hipEventElapsedTime(&ms, ev.a, ev.b));
     *ms_avg = (double)ms / reps;
     return CGH_OK;
 }
 
-int cgh_time_copy(void *d_dst, const void *d_src, size_t bytes, int reps, double *ms_avg)
+// variant = unroll (1 | 2 | 4 | 8) + 16 * (non-temporal loads) + 32 * (non-temporal stores) + 256 * workgroups per CU (0 -> 64)
+int cgh_time_copy_variant(void *d_dst, const void *d_src, size_t bytes, int reps, int variant, double *ms_avg)
 {
     CGH_REQUIRE_READY(CGH_ENODEV);
-    if (bytes % 16 || reps < 1) return CGH_EINVAL;
-    hipStream_t s = g_cgh.stream;
-    hipEvent_t  a, b;
-    CGH_HIP(hipEventCreate(&a));
-    CGH_HIP(hipEventCreate(&b));
-    const int grid = g_cgh.num_cu * 8;
-    hipLaunchKernelGGL(copy16, dim3(grid), dim3(256), 0, s, (const uint4 *)d_src, (uint4 *)d_dst, bytes / 16);
-    CGH_HIP(hipEventRecord(a, s));
-    for (int k = 0; k < reps; ++k)
-        hipLaunchKernelGGL(copy16, dim3(grid), dim3(256), 0, s, (const uint4 *)d_src, (uint4 *)d_dst, bytes / 16);
-    CGH_HIP(hipEventRecord(b, s));
+    if (bytes % 16 || reps < 1 || !d_dst || !d_src || !ms_avg) return CGH_EINVAL;
+    hipStream_t   s = g_cgh.stream;
+    const int     un = variant & 15, wgs = (variant >> 8) > 0 ? (variant >> 8) : 64;
+    const bool    ntl = (variant & 16) != 0, nts = (variant & 32) != 0;
+    const int     grid = g_cgh.num_cu * wgs;
+    const size_t  count = bytes / 16;
+    timing_events ev;
+    CGH_HIP(hipEventCreate(&ev.a));
+    CGH_HIP(hipEventCreate(&ev.b));
+    for (int k = 0; k <= reps; ++k) {  // (the first launch is a warm-up)
+        if (k == 1) CGH_HIP(hipEventRecord(ev.a, s));
+#define CGH_COPY(U, L, S) hipLaunchKernelGGL((copy16<U, L, S>), dim3(grid), dim3(256), 0, s, (const u4_t *)d_src, (u4_t *)d_dst, count)
+        if (un == 8) {
+            if (ntl && nts) CGH_COPY(8, true, true);
+            else if (ntl) CGH_COPY(8, true, false);
+            else if (nts) CGH_COPY(8, false, true);
+            else CGH_COPY(8, false, false);
+        } else if (un == 4) {
+            if (ntl && nts) CGH_COPY(4, true, true);
+            else if (ntl) CGH_COPY(4, true, false);
+            else if (nts) CGH_COPY(4, false, true);
+            else CGH_COPY(4, false, false);
+        } else if (un == 2) {
+            if (ntl && nts) CGH_COPY(2, true, true);
+            else CGH_COPY(2, false, false);
+        } else if (un == 1) {
+            if (ntl && nts) CGH_COPY(1, true, true);
+            else CGH_COPY(1, false, false);  // round 2's yardstick, kept for comparison
+        } else {
+            cgh_set_error("cgh_time_copy_variant: unroll %d is not built (1, 4, 8)", un);
+            return CGH_EINVAL;
+        }
+#undef CGH_COPY
+    }
+    CGH_HIP(hipEventRecord(ev.b, s));
     CGH_HIP(hipStreamSynchronize(s));
     float ms = 0.f;
-    CGH_HIP(hipEventElapsedTime(&ms, a, b));
-    (void)hipEventDestroy(a);
-    (void)hipEventDestroy(b);
+    CGH_HIP(hipEventElapsedTime(&ms, ev.a, ev.b));
     *ms_avg = (double)ms / reps;
     return CGH_OK;
+}
+
+// the yardstick itself: 4 loads in flight per lane, non-temporal loads and stores, 64 workgroups per CU (tools/quick_copy.py,
+// profiles/r03_copy_variants.txt: the best of the variants on MI355X, 6.2 TB/s read + written)
+int cgh_time_copy(void *d_dst, const void *d_src, size_t bytes, int reps, double *ms_avg)
+{
+    return cgh_time_copy_variant(d_dst, d_src, bytes, reps, 4 + 16 + 32, ms_avg);
 }
 
 // Read-only ceiling: `bytes` streamed from d_src once per repetition (16-byte non-temporal loads), nothing written.
@@ -269,21 +322,19 @@ int cgh_time_read(const void *d_src, void *d_sink_8k, size_t bytes, int reps, do
     CGH_REQUIRE_READY(CGH_ENODEV);
     if (bytes % 16 || reps < 1 || !d_src || !d_sink_8k) return CGH_EINVAL;
     hipStream_t s = g_cgh.stream;
-    hipEvent_t  a, b;
-    CGH_HIP(hipEventCreate(&a));
-    CGH_HIP(hipEventCreate(&b));
-    const int grid = g_cgh.num_cu * 8;  // <= 2048 workgroups: the sink holds 8 KiB
+    const int   grid = g_cgh.num_cu * 8;  // <= 2048 workgroups: the sink holds 8 KiB
     if (grid > 2048) return CGH_EINVAL;
+    timing_events ev;
+    CGH_HIP(hipEventCreate(&ev.a));
+    CGH_HIP(hipEventCreate(&ev.b));
     hipLaunchKernelGGL(read16, dim3(grid), dim3(256), 0, s, (const u4_t *)d_src, (unsigned *)d_sink_8k, bytes / 16);
-    CGH_HIP(hipEventRecord(a, s));
+    CGH_HIP(hipEventRecord(ev.a, s));
     for (int k = 0; k < reps; ++k)
         hipLaunchKernelGGL(read16, dim3(grid), dim3(256), 0, s, (const u4_t *)d_src, (unsigned *)d_sink_8k, bytes / 16);
-    CGH_HIP(hipEventRecord(b, s));
+    CGH_HIP(hipEventRecord(ev.b, s));
     CGH_HIP(hipStreamSynchronize(s));
     float ms = 0.f;
-    CGH_HIP(hipEventElapsedTime(&ms, a, b));
-    (void)hipEventDestroy(a);
-    (void)hipEventDestroy(b);
+    CGH_HIP(hipEventElapsedTime(&ms, ev.a, ev.b));
     *ms_avg = (double)ms / reps;
     return CGH_OK;
 }

@@ -16,6 +16,36 @@ void cgh_set_error(const char *fmt, ...)
     if (!getenv("CG_HIP_SILENT_ERRORS")) fprintf(stderr, "libcg_hip: %s\n", g_cgh.err);
 }
 
+// Values written by the cgh_config_* setters, by field offset: they outlive cgh_init and cgh_config_reload.
+namespace {
+struct cfg_override {
+    size_t  off;
+    int     bytes;
+    int64_t v;
+};
+cfg_override g_over[32];
+int          g_nover = 0;
+void record_override(size_t off, int bytes, int64_t v)
+{
+    for (int k = 0; k < g_nover; ++k)
+        if (g_over[k].off == off) {
+            g_over[k].v = v;
+            return;
+        }
+    if (g_nover < 32) g_over[g_nover++] = {off, bytes, v};
+}
+} // namespace
+void cgh_config_set(int *field, int v)
+{
+    *field = v;
+    record_override((size_t)((char *)field - (char *)&g_cfg), 4, v);
+}
+void cgh_config_set(int64_t *field, int64_t v)
+{
+    *field = v;
+    record_override((size_t)((char *)field - (char *)&g_cfg), 8, v);
+}
+
 // The CGH_* knobs (DESIGN.md lists them): read by cgh_init and cgh_config_reload only.
 static void read_env_knobs()
 {
@@ -46,6 +76,12 @@ static void read_env_knobs()
     if (getenv("CGH_PB_TARGET")) g_cfg.pb_target_entries = atoll(getenv("CGH_PB_TARGET"));
     g_cfg.pb_split = env_int("CGH_PB_SPLIT", g_cfg.pb_split);
     g_cfg.pb_ordered = env_int("CGH_PB_ORDERED", g_cfg.pb_ordered);
+    // what the host set through cgh_config_* wins over defaults and environment
+    for (int k = 0; k < g_nover; ++k) {
+        char *f = (char *)&g_cfg + g_over[k].off;
+        if (g_over[k].bytes == 4) *(int *)f = (int)g_over[k].v;
+        else *(int64_t *)f = g_over[k].v;
+    }
 }
 
 extern "C" {
@@ -116,10 +152,18 @@ int cgh_config_reload(void)
     return CGH_OK;
 }
 
+// Forget what the cgh_config_* setters set and read defaults + environment again.
+int cgh_config_reset(void)
+{
+    g_nover = 0;
+    if (g_cgh.ready) read_env_knobs();
+    return CGH_OK;
+}
+
 int cgh_config_sell_sigma(int sigma_rows)
 {
     if (sigma_rows < 0) return CGH_EINVAL;
-    if (sigma_rows) g_cfg.sell_sigma = sigma_rows < 64 ? 64 : sigma_rows;
+    if (sigma_rows) cgh_config_set(&g_cfg.sell_sigma, sigma_rows < 64 ? 64 : sigma_rows);
     return CGH_OK;
 }
 
@@ -131,11 +175,57 @@ int cgh_sync(void)
     return CGH_OK;
 }
 
+static long long g_alloc_calls = 0;
+/* how often the library has called hipMalloc through cgh_alloc since it was loaded (tests: a call that must not allocate) */
+long long cgh_alloc_calls(void) { return g_alloc_calls; }
+
+int cgh_mem_info(size_t *free_bytes, size_t *total_bytes)
+{
+    CGH_REQUIRE_READY(CGH_ENODEV);
+    size_t f = 0, t = 0;
+    CGH_HIP(hipMemGetInfo(&f, &t));
+    if (free_bytes) *free_bytes = f;
+    if (total_bytes) *total_bytes = t;
+    return CGH_OK;
+}
+
+/* Capture what the library queues on its compute stream from here on (global mode: an allocation or a synchronisation
+ * inside the captured region is an ERROR of the runtime, not a slow path) ... */
+int cgh_capture_begin(void)
+{
+    CGH_REQUIRE_READY(CGH_ENODEV);
+    CGH_HIP(hipStreamBeginCapture(g_cgh.stream, hipStreamCaptureModeGlobal));
+    return CGH_OK;
+}
+/* ... and end the capture, run the captured graph `replays` times on the same stream, and release it. */
+int cgh_capture_end_launch(int replays)
+{
+    CGH_REQUIRE_READY(CGH_ENODEV);
+    hipGraph_t     g = nullptr;
+    hipGraphExec_t ex = nullptr;
+    CGH_HIP(hipStreamEndCapture(g_cgh.stream, &g));
+    if (!g) {
+        cgh_set_error("cgh_capture_end_launch: the capture was invalidated");
+        return CGH_EHIP;
+    }
+    hipError_t e = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
+    for (int k = 0; e == hipSuccess && k < replays; ++k) e = hipGraphLaunch(ex, g_cgh.stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(g_cgh.stream);
+    if (ex) (void)hipGraphExecDestroy(ex);
+    (void)hipGraphDestroy(g);
+    if (e != hipSuccess) {
+        cgh_set_error("cgh_capture_end_launch: %s", hipGetErrorString(e));
+        return CGH_EHIP;
+    }
+    return CGH_OK;
+}
+
 void *cgh_alloc(size_t bytes)
 {
     CGH_REQUIRE_READY(nullptr);
     void *p = nullptr;
     if (bytes == 0) bytes = 16;
+    ++g_alloc_calls;
     hipError_t e = hipMalloc(&p, bytes);
     if (e != hipSuccess) {
         cgh_set_error("cgh_alloc(%zu): %s", bytes, hipGetErrorString(e));

@@ -609,11 +609,11 @@ extern "C" int cgh_config_csrb(int rpw, int slab_bits, int wgs_per_cu, int windo
         cgh_set_error("cgh_config_csrb: rows per wave-block 512|1024|2048, slab bits 4..22 (0 = keep), window <= 64, quorum divisor 2..255");
         return CGH_EINVAL;
     }
-    if (rpw) g_cfg.csrb_rpw = rpw;
-    if (slab_bits) g_cfg.csrb_slab_bits = slab_bits;
-    g_cfg.csrb_wgs_per_cu = wgs_per_cu;
-    if (window >= 0) g_cfg.csrb_window = window;
-    if (quorum_div > 0) g_cfg.csrb_quorum_div = quorum_div;
-    if (lds_atomics >= 0) g_cfg.csrb_lds_atomics = lds_atomics != 0;
+    if (rpw) cgh_config_set(&g_cfg.csrb_rpw, rpw);
+    if (slab_bits) cgh_config_set(&g_cfg.csrb_slab_bits, slab_bits);
+    cgh_config_set(&g_cfg.csrb_wgs_per_cu, wgs_per_cu);
+    if (window >= 0) cgh_config_set(&g_cfg.csrb_window, window);
+    if (quorum_div > 0) cgh_config_set(&g_cfg.csrb_quorum_div, quorum_div);
+    if (lds_atomics >= 0) cgh_config_set(&g_cfg.csrb_lds_atomics, (int)(lds_atomics != 0));
     return CGH_OK;
 }

@@ -254,7 +254,9 @@ __global__ __launch_bounds__(SPAN / 16) void pb_accumulate(int B, const int *__r
             }
         }
         if constexpr (ORDERED) {
-            while (__hip_atomic_load(&ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != (int)pc) {
+            // acquire / release (an lgkmcnt wait each on gfx950): the adds below stay behind the ticket they wait for and
+            // ahead of the one they hand on, whatever the compiler would like to do with relaxed atomics to other addresses
+            while (__hip_atomic_load(&ticket, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != (int)pc) {
             }
         }
 #pragma unroll
@@ -263,7 +265,7 @@ __global__ __launch_bounds__(SPAN / 16) void pb_accumulate(int B, const int *__r
             if ((r[q] >> 16) != 0xffffu) unsafeAtomicAdd(&acc[r[q] >> 16], p[q].y);
         }
         if constexpr (ORDERED) {
-            if (lane == 0) __hip_atomic_store(&ticket, (int)pc + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (lane == 0) __hip_atomic_store(&ticket, (int)pc + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
     }
     __syncthreads();
@@ -474,9 +476,9 @@ extern "C" int cgh_config_pb(int span_bits, int64_t target_entries, int split, i
                       "ordered 0 | 1 (< 0 = keep)");
         return CGH_EINVAL;
     }
-    if (ordered >= 0) g_cfg.pb_ordered = ordered;
-    if (span_bits) g_cfg.pb_span_bits = span_bits;
-    if (target_entries) g_cfg.pb_target_entries = target_entries;
-    if (split) g_cfg.pb_split = split;
+    if (ordered >= 0) cgh_config_set(&g_cfg.pb_ordered, ordered);
+    if (span_bits) cgh_config_set(&g_cfg.pb_span_bits, span_bits);
+    if (target_entries) cgh_config_set(&g_cfg.pb_target_entries, target_entries);
+    if (split) cgh_config_set(&g_cfg.pb_split, split);
     return CGH_OK;
 }

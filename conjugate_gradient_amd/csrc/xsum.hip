@@ -14,6 +14,8 @@
 //                  the group and the cell that fails, then finalises like seq_sums (alpha / beta / residual / done)
 // Everything the driver skips was validated by integer arithmetic that is exact, so the result does not depend on
 // the prediction: a wrong prediction only sends a cell down the element-by-element path.
+#include <new>
+
 #include "cgh_internal.h"
 #include "device_utils.h"
 #include "xsum.h"
@@ -28,6 +30,7 @@ struct cgh_xsum {
     double     *xfer = nullptr;      // [4]: the two sums on their way to the finalising workgroup, its ticket
     unsigned   *ready = nullptr;     // [2][batches of 64 groups]: groups summarised so far in the running fused launch (zero between launches)
     xs_summary *batches = nullptr;   // [2][batches]: the join of each batch's group summaries (fused launch)
+    bool        owns = true;         // false: object and arrays live in storage of the caller's (cgh_xsum_place)
 };
 
 namespace {
@@ -357,6 +360,14 @@ __device__ __forceinline__ void xs_store_words_agent(unsigned long long *dst, co
 {
     for (int i = threadIdx.x; i < words; i += blockDim.x) __hip_atomic_store(dst + i, src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// Every vector-memory store this wave has issued so far has been acknowledged -- for the write-through (agent-scope,
+// sc1) stores above: by the memory side, not by the XCD's L2.  A workgroup-scope release emits no such wait on gfx950, and
+// an agent-scope release fence would add a write-back of the whole L2 (see above); the count that follows is only ever
+// added after every wave of the workgroup has passed this wait and a barrier.
+__device__ __forceinline__ void xs_stores_acknowledged() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// The driver's side: a flag / count was read with an agent-scope load; the agent-scope loads of what it guards must not
+// be moved above it by the compiler (the hardware issues them in order, after the value they depend on has arrived).
+__device__ __forceinline__ void xs_compiler_acquire() { asm volatile("" ::: "memory"); }
 __device__ __forceinline__ xs_summary xs_load_agent(const xs_summary *src)
 {
     const unsigned long long *d = reinterpret_cast<const unsigned long long *>(src);
@@ -569,8 +580,8 @@ __device__ __forceinline__ void xs_summarize_body(xsm_shared<(KIND == XS_BOTH_SA
         for (int slot = S0; slot <= S1; ++slot)
             xs_store_words_agent(reinterpret_cast<unsigned long long *>(cells + slot * ncells + c0),
                                  reinterpret_cast<const unsigned long long *>(&sm[slot][pass * 16]), ccnt * 5);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __syncthreads();
+        xs_stores_acknowledged();  // every wave's write-through stores are in memory ...
+        __syncthreads();            // ... before the workgroup is counted
         int *last = reinterpret_cast<int *>(&red[0]);
         if (threadIdx.x == 0) {
 #pragma unroll
@@ -588,7 +599,7 @@ __device__ __forceinline__ void xs_summarize_body(xsm_shared<(KIND == XS_BOTH_SA
             if (lane < 5)
                 __hip_atomic_store(reinterpret_cast<unsigned long long *>(batches + (wave - S0) * nbatch + g) + lane, readlane_words(j, lane),
                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            xs_stores_acknowledged();  // (one wave: the batch's summary is in memory before its flag goes up)
             if (lane == 0)
                 __hip_atomic_fetch_add(ready + (wave - S0) * nbatch + g, XS_BATCH_READY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
@@ -620,7 +631,7 @@ __device__ __forceinline__ void xs_summarize_body(xsm_shared<(KIND == XS_BOTH_SA
                                    reinterpret_cast<const unsigned long long *>(gq + slot)[threadIdx.x], __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_AGENT);
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // every wave's write-through stores have been acknowledged ...
+        xs_stores_acknowledged();  // every wave's write-through stores have been acknowledged by memory ...
         __syncthreads();
         int *last = reinterpret_cast<int *>(&red[0]);            // (red: 4 doubles, dead by now)
         const int64_t bb = g >> 6;
@@ -642,7 +653,7 @@ __device__ __forceinline__ void xs_summarize_body(xsm_shared<(KIND == XS_BOTH_SA
             if (lane < 5)
                 __hip_atomic_store(reinterpret_cast<unsigned long long *>(batches + (wave - S0) * nbatch + bb) + lane,
                                    readlane_words(j, lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            xs_stores_acknowledged();  // (one wave: the batch's summary is in memory before its flag goes up)
             if (lane == 0)
                 __hip_atomic_fetch_add(ready + (wave - S0) * nbatch + bb, XS_BATCH_READY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
@@ -1114,6 +1125,7 @@ __device__ void xr_fetch_ahead(xr_shared &S, int slot, int64_t n, const double *
             if ((unsigned)__builtin_amdgcn_readfirstlane((int)f) >= ready_at) break;
             __builtin_amdgcn_s_sleep(4);
         }
+        xs_compiler_acquire();
         if (xr_peek(&S.walked) > bb) continue;
         if (xr_peek(&S.abort) || wall_clock64() - t0 > XR_PATIENCE) return;
         const int64_t c0 = (int64_t)bb * XS_GROUP;
@@ -1168,6 +1180,7 @@ __device__ double xr_sum(xr_shared &S, int slot, int64_t n, const double *__rest
         unsigned  f = 0;
         if (lane < cnt) f = __hip_atomic_load(ready + cur + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const unsigned long long rdy = __ballot(f >= ready_at);
+        xs_compiler_acquire();  // what the flags guard is loaded (agent scope) after them
         const int                m = ~rdy ? (int)__builtin_ctzll(~rdy) : 64;
         if (m == 0) {
             if (wall_clock64() - t0 > XR_PATIENCE) {
@@ -1281,9 +1294,11 @@ __global__ __launch_bounds__(256) void xs_fused(int64_t n, const double *__restr
     typedef xsm_shared<ND> sum_shared;
     constexpr size_t       LDS = sizeof(sum_shared) > sizeof(xr_shared) ? sizeof(sum_shared) : sizeof(xr_shared);
     __shared__ __attribute__((aligned(16))) unsigned char raw[LDS];
-    // every workgroup of the launch takes the same side: the flag only changes when a driver finalises, after the last
-    // summary of the launch
-    if (done != nullptr && mode != 3 && mode != 0 && *done != 0) return;
+    // Drivers and summarising workgroups of one launch all take the same side: the flag only changes when a driver
+    // finalises, after the last summary of the launch.  The workgroups that only carry x += alpha p are not waited for by
+    // anyone: one that starts after the driver has finalised a CONVERGING iteration finds the flag naming this very
+    // iteration and still owes its rows their update (as cg_update_xp: frozen means an EARLIER iteration converged).
+    const int frozen_at = done != nullptr && mode != 3 && mode != 0 ? *done : 0;
     const int64_t nbatch = FLAT ? ngroups : (ngroups + 63) / 64;
     if (blockIdx.x >= (unsigned)ND) {
         unsigned sb = blockIdx.x - ND;  // the workgroup's number among those that are no drivers
@@ -1294,17 +1309,20 @@ __global__ __launch_bounds__(256) void xs_fused(int64_t n, const double *__restr
             if (xu_x != nullptr) {
                 const unsigned k = sb / 5, r = sb % 5;
                 if (r == 4) {
-                    xs_update_x(n, xu_x, xu_p, hist, iter, done, k);
+                    const int it = iter ? iter : done[1];  // (replayed launches: the iteration number comes from the device)
+                    if (frozen_at == 0 || frozen_at == it) xs_update_x(n, xu_x, xu_p, hist, it, done, k);
                     return;
                 }
                 sb = k * 4 + r;
                 if ((int64_t)sb >= ngroups) return;
             }
         }
+        if (frozen_at != 0) return;
         xs_summarize_body<KIND, FLAT, true>(*reinterpret_cast<sum_shared *>(raw), sb, n, a, b, c, ncells, ngroups, cellsum, groupsum, gprefix,
                                              cells, groups, nullptr, ready, batches, nbatch);
         return;
     }
+    if (frozen_at != 0) return;
     const int  slot = S0 + (int)blockIdx.x;
     xr_shared &S = *reinterpret_cast<xr_shared *>(raw);
     if (threadIdx.x < XR_CHAINS) S.chain_cell[threadIdx.x] = -1;
@@ -1433,9 +1451,48 @@ cgh_xsum *cgh_xsum_create(int64_t n)
     return w;
 }
 
+// The same workspace laid out in memory the caller already holds -- nothing is allocated, on the host or on the device
+// (cgh_cg_solve_noalloc: its built-in __device__ array).  obj: host storage for the descriptor (cgh_xsum_object_bytes());
+// dev: 256-byte aligned device memory of at least cgh_xsum_device_bytes(n).  The counters the fused launch expects to find
+// at zero are cleared on stream s (a previous call may have been cut short).  cgh_xsum_free leaves all of it alone.
+static size_t xs_up256(size_t b) { return (b + 255) & ~(size_t)255; }
+size_t cgh_xsum_object_bytes(void) { return sizeof(cgh_xsum); }
+size_t cgh_xsum_device_bytes(int64_t n)
+{
+    const size_t ncells = (size_t)((n + XS_CELL - 1) / XS_CELL), ngroups = (ncells + XS_GROUP - 1) / XS_GROUP;
+    const size_t nready = 2 * ((ngroups + 63) / 64 > 32 ? (ngroups + 63) / 64 : 32);
+    return xs_up256(sizeof(double) * 2 * ncells) + 2 * xs_up256(sizeof(double) * 2 * ngroups) + xs_up256(sizeof(xs_summary) * 2 * ncells) +
+           xs_up256(sizeof(xs_summary) * 2 * ngroups) + xs_up256(sizeof(double) * 4) + xs_up256(sizeof(unsigned) * nready) +
+           xs_up256(sizeof(xs_summary) * nready);
+}
+cgh_xsum *cgh_xsum_place(void *obj, size_t obj_bytes, int64_t n, void *dev, size_t dev_bytes, hipStream_t s)
+{
+    if (n <= 0 || !obj || !dev || obj_bytes < sizeof(cgh_xsum) || dev_bytes < cgh_xsum_device_bytes(n) || (reinterpret_cast<uintptr_t>(dev) & 255u))
+        return nullptr;
+    cgh_xsum *w = new (obj) cgh_xsum();
+    w->owns = false;
+    w->n = n;
+    w->ncells = (n + XS_CELL - 1) / XS_CELL;
+    w->ngroups = (w->ncells + XS_GROUP - 1) / XS_GROUP;
+    const size_t nready = 2 * (size_t)((w->ngroups + 63) / 64 > 32 ? (w->ngroups + 63) / 64 : 32);
+    char *at = (char *)dev;
+    auto  take = [&at](size_t bytes) { char *p = at; at += xs_up256(bytes); return (void *)p; };
+    w->cellsum = (double *)take(sizeof(double) * 2 * (size_t)w->ncells);
+    w->groupsum = (double *)take(sizeof(double) * 2 * (size_t)w->ngroups);
+    w->gprefix = (double *)take(sizeof(double) * 2 * (size_t)w->ngroups);
+    w->cells = (xs_summary *)take(sizeof(xs_summary) * 2 * (size_t)w->ncells);
+    w->groups = (xs_summary *)take(sizeof(xs_summary) * 2 * (size_t)w->ngroups);
+    w->xfer = (double *)take(sizeof(double) * 4);
+    w->ready = (unsigned *)take(sizeof(unsigned) * nready);
+    w->batches = (xs_summary *)take(sizeof(xs_summary) * nready);
+    if (hipMemsetAsync(w->xfer, 0, sizeof(double) * 4, s) != hipSuccess || hipMemsetAsync(w->ready, 0, sizeof(unsigned) * nready, s) != hipSuccess)
+        return nullptr;
+    return w;
+}
+
 void cgh_xsum_free(cgh_xsum *w)
 {
-    if (!w) return;
+    if (!w || !w->owns) return;
     cgh_free(w->cellsum);
     cgh_free(w->groupsum);
     cgh_free(w->gprefix);

@@ -121,6 +121,9 @@ int64_t cgh_pb_partition_host(int64_t G, const int64_t *cum, int max_groups, int
 /* The CGH_* environment knobs (DESIGN.md lists them) are read ONCE, by cgh_init, never in a launch path; a host that
  * changes the environment afterwards (tests do) calls this to have them read again. */
 int     cgh_config_reload(void);
+/* Values set through cgh_config_csrb / cgh_config_sell_sigma / cgh_config_pb win over defaults and environment and stay in
+ * force across cgh_init and cgh_config_reload; this forgets them (defaults + environment again).  Tests call it between cases. */
+int     cgh_config_reset(void);
 /* Host-side planner of the column-blocked CSR (no GPU needed; exported for tests): deals nseg segments of the given
  * weights (entries) to ceil(nseg/spb) blocks of at most spb segments each, heaviest first to the lightest block with a
  * free slot.  seg_block[s], seg_slot[s] receive the placement.  Returns the number of blocks. */
@@ -183,8 +186,8 @@ int cgh_cg_solve(const cgh_matrix *m, const double *d_b, double *d_x,
  * hipMalloc: code under HIP graph capture, tight serving loops that solve one small system after another, harnesses that
  * forbid allocation.  It is cgh_cg_solve (same kernels, same launch shapes, same bits) with the solver's workspace
  * (r, p, A p, the per-workgroup partials, the converged flag) in a __device__ array built into the library: 25.2 MB
- * that every GPU the library runs on holds until the process ends.  Limits: at most 2^20 = 1048576 rows; strict = 1
- * only below 4096 rows (CGH_XSUM_MIN_ROWS; longer strict sums need their own allocated workspace) -- anything else is
+ * that every GPU the library runs on holds until the process ends (26.2 MB with the workspace of the order-exact sums that
+ * strict = 1 uses from 4096 rows on).  Limit: at most 2^20 = 1048576 rows, and a matrix with rows -- anything else is
  * refused with CGH_EINVAL and a message.  Asynchronous: all max_iter-1 iterations are queued on the library's stream
  * (the device freezes x, r, p at the converging iteration) and the call returns; after cgh_sync() d_x holds the
  * solution, d_history[4*k..] = { l1norm(r)/2, r.r, alpha, beta } for k = 0 .. converging iteration (4*max_iter doubles,
@@ -193,6 +196,15 @@ int cgh_cg_solve(const cgh_matrix *m, const double *d_b, double *d_x,
  * a GPU (two host threads) race. */
 int cgh_cg_solve_noalloc(const cgh_matrix *m, const double *d_b, double *d_x, int max_iter, double tol, int strict,
                          double *d_history, int *d_status);
+
+/* Helpers for such callers and for the test of the entry point above: number of device allocations the library has made
+ * so far (cgh_alloc -> hipMalloc); hipMemGetInfo of the current device; capture of everything the library queues on its
+ * compute stream between the two calls into a HIP graph (global capture mode: hipMalloc, hipFree and synchronisations
+ * inside it fail), which cgh_capture_end_launch instantiates, replays `replays` times, waits for and releases. */
+long long cgh_alloc_calls(void);
+int       cgh_mem_info(size_t *free_bytes, size_t *total_bytes);
+int       cgh_capture_begin(void);
+int       cgh_capture_end_launch(int replays);
 
 /* Resumable form of the same loop (what cgh_cg_solve is built from): the workspace lives in the
  * solver, iterations are queued asynchronously in batches, the host polls when it chooses. */
@@ -292,6 +304,7 @@ int cgh_dist_group_iterate(cgh_dist **ranks, int nranks, int count);
 int     cgh_dist_width(const cgh_dist *d);
 int64_t cgh_dist_halo(const cgh_dist *d);
 int     cgh_dist_download_local(const cgh_dist *d, double *diag, double *ell_vals, int *ell_cols);
+const double *cgh_dist_vector(const cgh_dist *d, int which);   /* device pointer to r (0), p (1) or A p (2) of the solve in flight */
 /* Peer-to-peer halo exchange (no library in the loop): each rank deposits its boundary entries of p straight into a
  * buffer of the neighbour (hipIpc) and raises a flag; see dist.hip.  With an RCCL communicator whose peer-to-peer path
  * is up, cgh_dist_from_partition / cgh_dist_poisson connect it by themselves (collectively: every rank must create
@@ -309,6 +322,9 @@ int     cgh_dist_loopback(cgh_dist *d);
 int cgh_time_spmv(const cgh_matrix *m, const double *d_x, double *d_y, int reps, double *ms_avg);
 /* float4-style device copy of `bytes` bytes, `reps` times: the attainable-HBM yardstick (ms per copy). */
 int cgh_time_copy(void *d_dst, const void *d_src, size_t bytes, int reps, double *ms_avg);
+/* the same with the copy's shape chosen by the caller: variant = loads in flight per lane (1 | 2 | 4 | 8) + 16 (non-temporal
+ * loads) + 32 (non-temporal stores) + 256 * workgroups per CU (0 = 64); cgh_time_copy is variant 4 + 16 + 32 */
+int cgh_time_copy_variant(void *d_dst, const void *d_src, size_t bytes, int reps, int variant, double *ms_avg);
 /* profile of the serial walks of the order-exact sums (xsum.hip: XS_PROF_ADD): 16 zeroed 64-bit device words, or NULL */
 void cgh_xsum_set_prof(void *dev_16_words);
 /* read-only stream of `bytes` from d_src (d_sink_8k: 8 KiB of device scratch): the ceiling for read-dominated kernels */

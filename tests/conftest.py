@@ -15,11 +15,12 @@ import pytest  # noqa: E402
 @pytest.fixture(autouse=True)
 def _reload_knobs_after_test():
     """The library reads its CGH_* environment knobs once (cgh_init) or on cgh_config_reload(); tests that set one call
-    gpu_common.setknob, and once monkeypatch has restored the environment the knobs are read again here."""
+    gpu_common.setknob, and once monkeypatch has restored the environment the knobs are read again here -- by
+    cgh_config_reset(), which also forgets what a test set through the cgh_config_* setters (those outlive a reload)."""
     yield
     try:
         import conjugate_gradient_amd as cga
         if cga.binding._inited is not None:
-            cga.lib().cgh_config_reload()
+            cga.lib().cgh_config_reset()
     except Exception:
         pass

@@ -70,12 +70,16 @@ def test_strict_cg_through_parallel_sums(cga, monkeypatch, tag):
     assert np.array_equal(bits(x.to_host()), bits(g["cg_x"]))
 
 
-def test_full_size_256cubed_strict_bit_exact(cga):
+def test_full_size_256cubed_strict_bit_exact(cga, monkeypatch):
     """BASELINE config 3 at full size: strict mode (parallel order-exact sums) against the reference's own arithmetic
-    on the host (oracle/_ref/libref.so when present, else the oracle port): (res, rr, alpha, beta) and x bit-identical."""
+    on the host (oracle/_ref/libref.so when present, else the oracle port), 50 iterations: (res, rr, alpha, beta) and x
+    bit-identical.  Then a solve that CONVERGES at this size (tolerance taken from the host trajectory, iterations queued
+    past it): the launch of the sums of r carries x += alpha p in workgroups nobody waits for, and at 256^3 the grid (2562
+    workgroups) exceeds what the chip holds at once -- x at the converging iteration must equal the reference's all the
+    same, with the x update riding along and without."""
     import ctypes as C
     import os
-    N, iters = 256, 6
+    N, iters = 256, 50
     n = N ** 3
     b = cga.DeviceVector(n); x = cga.DeviceVector(n)
     A = cga.Matrix.poisson(N, N, N, 7, 0x5EED0001, cga.LAYOUT_ELL, b)
@@ -100,19 +104,35 @@ def test_full_size_256cubed_strict_bit_exact(cga):
     xr = np.zeros(n); r = bh.copy(); p = bh.copy(); Ap = np.empty(n)
     rr = dot(r, r)
     want = [[l1(r) / 2.0, rr, np.nan, np.nan]]
-    for _ in range(iters):
+    low, stop_at, x_stop = want[0][0], 0, None     # first iteration >= 20 whose residual is below every earlier one
+    for it in range(1, iters + 1):
         mv(p, Ap)
         alpha = rr / dot(p, Ap)
         axpy(xr, p, alpha, xr); axpy(r, Ap, -alpha, r)
         rr_new = dot(r, r)
         beta = rr_new / rr
         want.append([l1(r) / 2.0, rr_new, alpha, beta])
+        if want[-1][0] < low:
+            low = want[-1][0]
+            if it >= 20 and stop_at == 0:
+                stop_at, x_stop = it, xr.copy()
         axpy(r, p, beta, p)
         rr = rr_new
     rep, hist = cga.cg_solve(A, b, x, fixed_iters=iters, strict=1)
     print("\n[256^3 strict] %d iterations in %.2f ms = %.3f ms/iteration" % (iters, rep.solve_ms, rep.solve_ms / iters))
     assert same_bits_nan(hist, np.array(want))
     assert np.array_equal(bits(x.to_host()), bits(xr))
+    assert stop_at > 0, "the residual of the 256^3 system did not fall between iterations 20 and 50"
+    tol = float(np.nextafter(want[stop_at][0], np.inf))     # res[stop_at] < tol <= every earlier residual
+    for xupd in ("1", "0"):
+        setknob(monkeypatch, "CGH_XSUM_XUPD", xupd)
+        x.zero()
+        rep, hist = cga.cg_solve(A, b, x, max_iter=iters + 1, tol=tol, strict=1, check_every=32)
+        assert rep.ret == stop_at + 1, (xupd, rep.ret, stop_at)
+        ref = np.array(want[:stop_at + 1]); ref[stop_at, 3] = np.nan     # the converging iteration computes no beta
+        assert same_bits_nan(hist, ref)
+        assert np.array_equal(bits(x.to_host()), bits(x_stop)), "x at the converging iteration (CGH_XSUM_XUPD=%s)" % xupd
+    setknob(monkeypatch, "CGH_XSUM_XUPD", "1")
 
 
 def test_random_trials_device(cga, monkeypatch):

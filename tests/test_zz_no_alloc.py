@@ -1,7 +1,12 @@
 """GPU: cgh_cg_solve_noalloc -- the one entry point that allocates nothing (workspace in a static __device__ array) --
 against cgh_cg_solve, the entry point it is a variant of: same kernels, same launch shapes, so the residual history, the
 solution and the converging iteration are bit-identical.  Two calls in a row, the second on a smaller system (the array
-keeps the first call's contents); then the sizes it must refuse.  No reference counterpart."""
+keeps the first call's contents); that the call really allocates nothing (the library's allocation counter and
+hipMemGetInfo stand still across it, on a matrix whose column dictionary no SpMV has built yet; the same call recorded
+under hipStreamBeginCapture in global mode, where hipMalloc is an error, and replayed); strict sums of long vectors from the
+same array; then what it must refuse.  No reference counterpart."""
+import ctypes as C
+
 import numpy as np
 import pytest
 
@@ -17,7 +22,40 @@ def cga():
     return m
 
 
-def _both(cga, tag, strict, layout=None):
+def _free_bytes(cga):
+    f, t = C.c_size_t(), C.c_size_t()
+    cga.check(cga.lib().cgh_mem_info(C.byref(f), C.byref(t)), "cgh_mem_info")
+    return f.value
+
+
+_warm = set()
+
+
+def _noalloc(cga, A, b, n, max_iter, tol, strict, capture=False, check_free=True):
+    """one call of the entry point on buffers made beforehand; asserts that the call itself allocated nothing"""
+    L = cga.lib()
+    x2 = cga.DeviceVector.from_host(np.full(n, 7.0))
+    hist_d = cga.DeviceVector.from_host(np.full(4 * max_iter, -3.0))
+    status = cga.DeviceVector.from_host(np.full(4, -1, dtype=np.int32))
+    cga.check(L.cgh_sync())
+    calls0, free0 = L.cgh_alloc_calls(), _free_bytes(cga)
+    if capture:
+        cga.check(L.cgh_capture_begin(), "cgh_capture_begin")
+    rc = L.cgh_cg_solve_noalloc(A.h, b.ptr, x2.ptr, max_iter, tol, strict, hist_d.ptr, status.ptr)
+    calls1 = L.cgh_alloc_calls()
+    if capture:
+        # nothing ran yet: the launches were recorded.  Replay the graph twice -- the second replay starts from the first
+        # one's x, history and workspace and must leave the same bits.
+        cga.check(L.cgh_capture_end_launch(2), "cgh_capture_end_launch")
+    cga.check(rc, "cgh_cg_solve_noalloc")
+    cga.check(L.cgh_sync())
+    assert calls1 == calls0, "cgh_cg_solve_noalloc called cgh_alloc %d times" % (calls1 - calls0)
+    if not capture and check_free:
+        assert _free_bytes(cga) == free0, "free device memory changed across cgh_cg_solve_noalloc"
+    return x2, hist_d.to_host().reshape(max_iter, 4), int(status.to_host()[0])
+
+
+def _both(cga, tag, strict, layout=None, capture=False):
     s, g = inputs(tag), golden(tag)
     n, K = s["n"], int(g["K_full"])
     if layout is None:
@@ -26,18 +64,26 @@ def _both(cga, tag, strict, layout=None):
         A = cga.Matrix.from_coo(n, s["diag"], s["upper"], s["rows"], s["cols"], layout)
     b = cga.DeviceVector.from_host(s["source"])
     max_iter, tol = int(g["max_iter"]), float(g["tol"])
-    # the new entry point first, on a matrix no SpMV has touched yet
-    x2 = cga.DeviceVector.from_host(np.full(n, 7.0))
-    hist_d = cga.DeviceVector.from_host(np.full(4 * max_iter, -3.0))
-    status = cga.DeviceVector.from_host(np.full(4, -1, dtype=np.int32))
-    cga.check(cga.lib().cgh_cg_solve_noalloc(A.h, b.ptr, x2.ptr, max_iter, tol, strict, hist_d.ptr, status.ptr), "cgh_cg_solve_noalloc")
-    cga.check(cga.lib().cgh_sync())
-    done = int(status.to_host()[0])
-    h2 = hist_d.to_host().reshape(max_iter, 4)
+    # Warm-up on a twin of the matrix: the FIRST launch of a kernel in a process makes the HIP runtime load its code object
+    # and grow its own pools (hipMemGetInfo moved by 4 MiB across the very first call), which is no allocation of this
+    # library's and happens once per process whatever the entry point.
+    if (tag, strict, layout) not in _warm:
+        _warm.add((tag, strict, layout))
+        A0 = (cga.Matrix.from_ell(n, K, s["diag"], g["ell_full_vals"], g["ell_full_cols"]) if layout is None
+              else cga.Matrix.from_coo(n, s["diag"], s["upper"], s["rows"], s["cols"], layout))
+        _noalloc(cga, A0, b, n, max_iter, tol, strict, capture=False, check_free=False)
+        A0.free()
+    # the new entry point first, on a matrix no SpMV has touched yet (its column dictionary is not built: dict_offsets -1)
+    if layout is None:
+        assert A.dict_offsets == -1
+    x2, h2, done = _noalloc(cga, A, b, n, max_iter, tol, strict, capture)
     x1 = cga.DeviceVector(n)
     rep, hist = cga.cg_solve(A, b, x1, max_iter=max_iter, tol=tol, strict=strict)
-    assert rep.ret > 0 and done == rep.iterations and done + 1 == rep.ret
-    assert same_bits_nan(h2[:done + 1], hist)
+    if rep.ret > 0:
+        assert done == rep.iterations and done + 1 == rep.ret
+    else:                       # not converged within max_iter (cylinder_32k: the reference returns -1 too)
+        assert rep.ret == -1 and done == 0 and rep.iterations == max_iter - 1
+    assert same_bits_nan(h2[:rep.iterations + 1], hist)
     assert np.array_equal(bits(x2.to_host()), bits(x1.to_host()))
     return rep.ret, int(g["cg_ret"][4])
 
@@ -47,13 +93,30 @@ def test_two_calls_in_a_row_second_smaller(cga):
     assert abs(ret - want) <= 1
     ret, want = _both(cga, "cylinder_2000", strict=0)     # smaller: the workspace still holds the 8000-row solve
     assert abs(ret - want) <= 1
-    ret, want = _both(cga, "cylinder_2000", strict=1)     # strict sums of a short vector need no workspace of their own:
+    ret, want = _both(cga, "cylinder_2000", strict=1)     # strict sums of a short vector: one lane adds, no workspace
     assert ret == want                                    # the reference's trajectory bit for bit (golden, via cgh_cg_solve)
     ret, want = _both(cga, "poisson7_16", strict=0, layout=1)   # CSR layout through the same entry point
 
 
+def test_strict_sums_of_long_vectors_from_the_same_array(cga):
+    """from 4096 rows on strict = 1 takes the order-exact parallel sums, whose summaries and counters now live in the tail
+    of the built-in array: the reference's trajectory bit for bit, larger system first, then a smaller one"""
+    ret, want = _both(cga, "cylinder_32k", strict=1)
+    assert ret == want
+    ret, want = _both(cga, "cylinder_8000", strict=1)
+    assert ret == want
+
+
+def test_recorded_under_stream_capture(cga):
+    """global capture mode turns any hipMalloc / hipFree / synchronisation inside the call into an error: the call records
+    cleanly, and the replayed graph gives cgh_cg_solve's bits"""
+    ret, want = _both(cga, "cylinder_8000", strict=0, capture=True)
+    assert abs(ret - want) <= 1
+    ret, want = _both(cga, "cylinder_2000", strict=1, capture=True)
+    assert ret == want
+
+
 def test_refuses_what_it_cannot_hold(cga):
-    import ctypes as C
     L = cga.lib()
     n = 128 * 128 * 80                                   # 1.3M rows > 2^20
     b = cga.DeviceVector(n); x = cga.DeviceVector(n)
@@ -67,8 +130,7 @@ def test_refuses_what_it_cannot_hold(cga):
         s, g = inputs("cylinder_8000"), golden("cylinder_8000")
         A2 = cga.Matrix.from_ell(s["n"], int(g["K_full"]), s["diag"], g["ell_full_vals"], g["ell_full_cols"])
         b2 = cga.DeviceVector.from_host(s["source"]); x2 = cga.DeviceVector(s["n"])
-        assert L.cgh_cg_solve_noalloc(A2.h, b2.ptr, x2.ptr, 10, 1e-6, 1, hist.ptr, status.ptr) != 0   # strict, 8000 rows >= 4096
-        assert b"strict" in L.cgh_last_error()
-        assert L.cgh_cg_solve_noalloc(A2.h, b2.ptr, x2.ptr, 0, 1e-6, 0, hist.ptr, status.ptr) != 0
+        assert L.cgh_cg_solve_noalloc(A2.h, b2.ptr, x2.ptr, 0, 1e-6, 0, hist.ptr, status.ptr) != 0     # max_iter < 1
+        assert L.cgh_cg_solve_noalloc(A2.h, None, x2.ptr, 10, 1e-6, 0, hist.ptr, status.ptr) != 0       # NULL argument
     finally:
         del os.environ["CG_HIP_SILENT_ERRORS"]
