@@ -67,6 +67,24 @@ class quiet_stdout:
         os.close(self.saved)
 
 
+def reference_library():
+    """(path, flags) of the reference compiled from its own sources (oracle/Makefile): the -march=x86-64-v3 twin when this
+    host has AVX2 + FMA + BMI2 (what the reference's own -march=native would at least use here), else the generic build."""
+    base = "gcc -std=c99 -fgnu89-inline -O3 -DNDEBUG -ffp-contract=off"
+    plain = os.path.join(ROOT, "oracle", "_ref", "libref.so")
+    v3 = os.path.join(ROOT, "oracle", "_ref", "libref_v3.so")
+    try:
+        with open("/proc/cpuinfo") as f:
+            flags = set(next(l for l in f if l.startswith("flags")).split())
+    except (OSError, StopIteration):
+        flags = set()
+    if os.path.exists(v3) and {"avx2", "fma", "bmi2"} <= flags:
+        return v3, base + " -march=x86-64-v3 -mtune=generic (the reference's Makefile says -march=native -mtune=native; the library is built in another container)"
+    if os.path.exists(plain):
+        return plain, base + " (no -march: built in another container; the reference's Makefile says -march=native)"
+    return None, ""
+
+
 def cpu_baseline(A, b_dev, budget_s=15.0):
     """Time the reference's CPU CG on the same matrix, 1 thread, bounded iterations."""
     n, K = A.n, A.K
@@ -77,8 +95,8 @@ def cpu_baseline(A, b_dev, budget_s=15.0):
     dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int)
     D = lambda a: a.ctypes.data_as(dp)  # noqa: E731
     I = lambda a: a.ctypes.data_as(ip)  # noqa: E731
-    ref_so = os.path.join(ROOT, "oracle", "_ref", "libref.so")
-    if os.path.exists(ref_so):
+    ref_so, ref_flags = reference_library()
+    if ref_so:
         kind = "reference"
         L = C.CDLL(ref_so)
         spmv = lambda: L.mv_ell_symmetric_full_colmajor(n, K, D(diag), D(ev), I(ec), D(b), D(x))  # noqa: E731
@@ -87,6 +105,7 @@ def cpu_baseline(A, b_dev, budget_s=15.0):
     else:
         import oracle_lib as O
         kind = "port"
+        ref_flags = "gcc -std=c99 -O3 -DNDEBUG -ffp-contract=off"
         L = O.lib()
         spmv = lambda: L.orc_mv_ell_symmetric_full_colmajor(n, K, D(diag), D(ev), I(ec), D(b), D(x))  # noqa: E731
         solve = lambda mi: L.orc_cg(4, n, D(diag), 0, D(ev), I(ec), None, K, D(b), D(x), mi, -1.0, None)  # noqa: E731
@@ -102,7 +121,7 @@ def cpu_baseline(A, b_dev, budget_s=15.0):
     alg = 12 * A.nnz_offdiag + 24 * n
     return {"value": iters / dt, "unit": "iterations/s", "cores": 1, "kind": kind,
             "sample": "%d CG iterations of the same %d-row matrix (plus the set-up SpMV), 1 thread, %.1f s; "
-                      "its SpMV alone: %.3f s = %.2f GB/s algorithmic" % (iters, n, dt, t_spmv, alg / t_spmv / 1e9)}
+                      "its SpMV alone: %.3f s = %.2f GB/s algorithmic; compiled with %s" % (iters, n, dt, t_spmv, alg / t_spmv / 1e9, ref_flags)}
 
 
 def cpu_baseline_csr(A_csr, b_dev, budget_s=15.0):
@@ -124,8 +143,8 @@ def cpu_baseline_csr(A_csr, b_dev, budget_s=15.0):
     dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int)
     D = lambda a: a.ctypes.data_as(dp)  # noqa: E731
     I = lambda a: a.ctypes.data_as(ip)  # noqa: E731
-    ref_so = os.path.join(ROOT, "oracle", "_ref", "libref.so")
-    if os.path.exists(ref_so):
+    ref_so, ref_flags = reference_library()
+    if ref_so:
         kind = "reference"
         L = C.CDLL(ref_so)
         spmv = lambda: L.mv_csr_symmetric(n, D(diag), D(uvals), I(ucols), I(urp), D(b), D(x))  # noqa: E731
@@ -134,6 +153,7 @@ def cpu_baseline_csr(A_csr, b_dev, budget_s=15.0):
     else:
         import oracle_lib as O
         kind = "port"
+        ref_flags = "gcc -std=c99 -O3 -DNDEBUG -ffp-contract=off"
         L = O.lib()
         spmv = lambda: L.orc_mv_csr_symmetric(n, D(diag), D(uvals), I(ucols), I(urp), D(b), D(x))  # noqa: E731
         solve = lambda mi: L.orc_cg(O.FMT_CSR, n, D(diag), U, D(uvals), I(urp), I(ucols), 0, D(b), D(x), mi, -1.0, None)  # noqa: E731
@@ -148,7 +168,7 @@ def cpu_baseline_csr(A_csr, b_dev, budget_s=15.0):
     alg = 12 * 2 * U + 24 * n
     return {"value": iters / dt, "unit": "iterations/s", "cores": 1, "kind": kind,
             "sample": "%d iterations of conjugate_gradient_csr on the strictly-upper CSR of the same %d-row matrix (plus the set-up "
-                      "SpMV), 1 thread, %.1f s; its mv_csr_symmetric alone: %.3f s = %.2f GB/s algorithmic" % (iters, n, dt, t_spmv, alg / t_spmv / 1e9)}
+                      "SpMV), 1 thread, %.1f s; its mv_csr_symmetric alone: %.3f s = %.2f GB/s algorithmic; compiled with %s" % (iters, n, dt, t_spmv, alg / t_spmv / 1e9, ref_flags)}
 
 
 def cpu_all_cores(A, b_dev, iters=40):
@@ -313,12 +333,15 @@ def main():
     }
     # HBM traffic of the SpMV from the PMC counters: collected in separate rocprofv3 passes (it cannot be read live) and
     # committed under profiles/ with its derivation; reported only for the workload it was measured on
-    for rnd in ("r02", "r01"):
-        tpath = os.path.join(ROOT, "profiles", "%s_traffic_%s.json" % (rnd, args.workload))
+    tname = args.workload + ("" if powerlaw or A.dict_offsets > 0 else "_int32cols")
+    for rnd in ("r03", "r02", "r01"):
+        tpath = os.path.join(ROOT, "profiles", "%s_traffic_%s.json" % (rnd, tname))
         if os.path.exists(tpath):
             with open(tpath) as f:
                 out["roofline"]["traffic"] = json.load(f)["hbm_bytes_per_launch"]
             out["roofline"]["traffic_source"] = "profiles/" + os.path.basename(tpath)
+            # the same fraction in REAL bytes: what the PMC counters saw move, over the kernel's time, against the peak
+            out["roofline"]["frac_real_bytes"] = out["roofline"]["traffic"] / (spmv_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
             break
     sv.free()
     # attainable ceiling next to the spec peak: device-to-device copy kernel, 1 GiB, bytes read + written
@@ -327,7 +350,7 @@ def main():
     dst = cga.DeviceVector(cbytes // 8)
     ms = C.c_double(0.0)
     cga.check(cga.lib().cgh_time_copy(dst.ptr, src.ptr, cbytes, 10, C.byref(ms)))
-    out["roofline"]["copy_ceiling_GBs"] = 2 * cbytes / (ms.value * 1e-3) / 1e9
+    out["roofline"]["copy_ceiling_GBs"] = 2 * cbytes / (ms.value * 1e-3) / 1e9   # 4 x 16-byte non-temporal loads in flight per lane, non-temporal stores
     out["roofline"]["frac_of_copy_ceiling"] = achieved / out["roofline"]["copy_ceiling_GBs"]
     # ... and a read-only stream (the SpMV reads 12 bytes for every byte it writes): bytes read / time
     sink = cga.DeviceVector(1024)

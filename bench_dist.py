@@ -209,8 +209,9 @@ def measure(rank, world, shape, seed, steps, warmup, p2p_in_force):
     cga.check(cga.lib().cgh_sync())
     barrier()
     spmv_ms = D.spmv_ms()
+    own = {"ms_per_step": dt / steps * 1e3, "spmv_ms": spmv_ms, "rows": int(nl), "halo_entries": int(D.n_halo)}
     dt, spmv_ms = cga.comm_allreduce([dt, spmv_ms], "max")      # slowest rank
-    nnz_total = cga.comm_allreduce([float(D.nnz_offdiag)], "sum")[0]   # exact: far below 2^53
+    nnz_total, halo_total = cga.comm_allreduce([float(D.nnz_offdiag), float(D.n_halo)], "sum")   # exact: far below 2^53
     hist = D.history(0, cap)
     finite = bool(np.all(np.isfinite(hist[1:, 0]))) and (not p2p_in_force or cga.lib().cgh_p2p_error() == 0)
     finite = cga.comm_allreduce([1.0 if finite else 0.0], "min")[0] == 1.0     # one verdict for all ranks
@@ -220,7 +221,39 @@ def measure(rank, world, shape, seed, steps, warmup, p2p_in_force):
     D.free()
     return {"finite": finite, "halo": halo, "n": n, "nnz_off": nnz_off, "alg_spmv": alg_spmv, "dt": dt, "spmv_ms": spmv_ms, "steps": steps,
             "ms_step": dt / steps * 1e3, "achieved": alg_spmv / (spmv_ms * 1e-3) / 1e9,
-            "res": [float(hist[0, 0]), float(hist[-1, 0])]}
+            "res": [float(hist[0, 0]), float(hist[-1, 0])], "own": own, "halo_total": int(halo_total)}
+
+
+def spmv_alone_ms(shape, rank, world, seed):
+    """this rank's slab as a matrix of its own (no neighbours, no halo columns): SpMV time inside a plain one-GPU loop.
+    The difference to the partitioned loop's SpMV is what the halo costs INSIDE the SpMV (deposit reads + exposed waits)."""
+    nx, ny, nz, points = shape
+    nzl = nz * (rank + 1) // world - nz * rank // world
+    nl = nx * ny * nzl
+    b = cga.DeviceVector(nl); x = cga.DeviceVector(nl)
+    A = cga.Matrix.poisson(nx, ny, nzl, points, seed, cga.LAYOUT_ELL, b)
+    sv = cga.Solver(A, 72)
+    sv.start(b, x, tol=-1.0, strict=0)
+    sv.iterate(10, 0)
+    sv.iterate(60, 1)
+    ms = sv.spmv_ms()
+    sv.free(); A.free()
+    return ms
+
+
+def allreduce_latencies(no_rccl):
+    """the two scalar all-reduces of an iteration, alone: 1000 exchanges back to back per transport, us per exchange"""
+    import ctypes as C
+    L = cga.lib()
+    out = {}
+    v = C.c_double()
+    if L.cgh_p2p_connected():
+        rc = L.cgh_comm_bench_allreduce(1000, 1, C.byref(v))
+        out["p2p_mailbox_us"] = v.value if rc == 0 else "failed: " + L.cgh_last_error().decode()
+    if not no_rccl:
+        rc = L.cgh_comm_bench_allreduce(1000, 0, C.byref(v))
+        out["rccl_us"] = v.value if rc == 0 else "failed: " + L.cgh_last_error().decode()
+    return out
 
 
 def run(args, rank, world, local_rank, shape, seed):
@@ -260,9 +293,41 @@ def run(args, rank, world, local_rank, shape, seed):
         m = measure(rank, world, shape, seed, args.steps, args.warmup, p2p)
     if m is None or not m["finite"]:
         raise SystemExit("bench_dist: non-finite residual: the iteration did not run")
+    # Self-diagnosis, one line per rank on stderr (a driver-run record can be read without a second run): which transport
+    # carries the reductions and the halo and why, both transports' probe timings, the two all-reduce latencies measured
+    # alone, this rank's own iteration and SpMV time, and what the halo costs inside the SpMV (against the same slab as a
+    # matrix without neighbours).
+    try:
+        lat = allreduce_latencies(no_rccl)
+        alone = spmv_alone_ms(shape, rank, world, seed)
+        diag = {"rank": rank, "of": world, "device": local_rank, "scalar_allreduce": path, "halo_exchange": m["halo"],
+                "transport_probe_us_per_iter": probe, "allreduce_alone_us_per_exchange": lat,
+                "p2p_error_word": int(cga.lib().cgh_p2p_error()), "last_library_message": cga.lib().cgh_last_error().decode()[:200],
+                "own_ms_per_step": m["own"]["ms_per_step"], "slowest_ms_per_step": m["ms_step"],
+                "own_spmv_ms": m["own"]["spmv_ms"], "same_slab_without_neighbours_spmv_ms": alone,
+                "halo_cost_inside_spmv_us": (m["own"]["spmv_ms"] - alone) * 1e3,
+                "rows": m["own"]["rows"], "halo_entries": m["own"]["halo_entries"]}
+    except Exception as e:  # noqa: BLE001  (a diagnostic must not cost the run its line)
+        diag = {"rank": rank, "diagnostics_failed": str(e)}
+    barrier()
+    sys.stderr.flush()
+    os.write(2, ("[cg_hip bench_dist] " + json.dumps(diag) + "\n").encode())   # one write: the ranks' lines do not interleave
     extra = None
     if args.workload == "p7_256" and not args.no_config4:
         extra = measure(rank, world, (512, 512, 512, 27), seed, min(args.steps, 20), min(args.warmup, 3), p2p)
+    cpu = None
+    if rank == 0 and not args.no_cpu_baseline and m["n"] <= (1 << 25):
+        # the reference's CPU path beside it (rank 0 only, the others wait at the last barrier): the WHOLE matrix, generated
+        # on this rank's GPU once the timed regions are over, handed to the same routine the one-GPU line uses
+        try:
+            import bench
+            bb = cga.DeviceVector(m["n"])
+            A1 = cga.Matrix.poisson(nx, ny, nz, points, seed, cga.LAYOUT_ELL, bb)
+            cpu = bench.cpu_baseline(A1, bb, budget_s=8.0)
+            A1.free()
+            del bb
+        except Exception as e:  # noqa: BLE001
+            cpu = {"error": str(e)}
     if rank == 0:
         out = {
             "metric": "CG iters/sec + SpMV achieved HBM GB/s (% of peak): value = CG iterations/s, the SpMV figures are in roofline",
@@ -286,6 +351,22 @@ def run(args, rank, world, local_rank, shape, seed):
                          "frac": m["achieved"] / (HBM_PEAK_GBS * world), "bytes_per_launch": int(m["alg_spmv"]),
                          "ms_per_launch": m["spmv_ms"], "traffic": None},
         }
+        # HBM bytes per launch: the PMC figure of the one-GPU launch of the same kernel family (separate rocprofv3 passes,
+        # profiles/) -- the N slabs together read the same matrix and vectors -- plus the 16 bytes per halo entry the
+        # deposit reads add (two tagged words); counters cannot be collected inside a driver-run multi-rank launch
+        root = os.path.dirname(os.path.abspath(__file__))
+        for rnd in ("r03", "r02", "r01"):
+            tpath = os.path.join(root, "profiles", "%s_traffic_%s.json" % (rnd, args.workload))
+            if os.path.exists(tpath):
+                with open(tpath) as f:
+                    one = json.load(f)["hbm_bytes_per_launch"]
+                out["roofline"]["traffic"] = int(one + 16 * m["halo_total"])
+                out["roofline"]["traffic_source"] = ("profiles/%s (one-GPU PMC passes of the same kernel family: %d bytes) + 16 bytes x %d halo entries "
+                                                     "read from the deposits; not collected in this run" % (os.path.basename(tpath), one, m["halo_total"]))
+                out["roofline"]["frac_real_bytes"] = out["roofline"]["traffic"] / (m["spmv_ms"] * 1e-3) / 1e9 / (HBM_PEAK_GBS * world)
+                break
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
         if extra is not None and extra["finite"]:
             out["config4"] = {"workload": "p27_512: 3-D 27-point Poisson 512^3, %d rows, %d off-diagonals, z-slabs over %d GPUs"
                                           % (extra["n"], extra["nnz_off"], world),

@@ -118,6 +118,7 @@ def lib():
     L.cgh_comm_init.argtypes = [C.c_int, C.c_int, C.c_char_p]
     L.cgh_comm_destroy.restype = None
     L.cgh_comm_allreduce_f64.argtypes = [dp, C.c_int, C.c_int]
+    L.cgh_comm_bench_allreduce.argtypes = [C.c_int, C.c_int, dp]
     L.cgh_p2p_local_handle.argtypes = [C.c_char_p]
     L.cgh_comm_init_local.argtypes = [C.c_int, C.c_int]
     L.cgh_dist_halo_descriptor.argtypes = [vp, C.c_char_p]

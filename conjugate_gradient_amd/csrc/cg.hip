@@ -312,9 +312,13 @@ static int enqueue_iterations(cgh_solver *sv, int count, int time_kernels, bool 
             rc = strict_sums(sv, dp, dAp, nullptr, 1, iter, s, pAp_presummed);
             if (rc) return rc;
             // with the parallel sums, the r update also leaves their per-cell approximate sums (one sweep over r less)
+            // (whole groups of the sums' hierarchy per workgroup, so that the group sums come out as well -- unless the sweep
+            // direction is reversed, or the sums are so short that their launch adds up the cell sums itself)
+            double *gsums = rev2 || cgh_xsum_cells(sv->xs) <= 4096 ? nullptr : cgh_xsum_groupsums(sv->xs);
             hipLaunchKernelGGL((cg_update_r<1, 3>), dim3(vg), dim3(CGH_BLOCK), 0, s, n, dr, (const double *)dAp,
                                (const double *)dA, gridA, dB, dh, iter, (const int *)dd, rev2, (const double *)nullptr,
-                               cgh_xsum_cellsums(sv->xs), cgh_xsum_cells(sv->xs));
+                               cgh_xsum_cellsums(sv->xs), cgh_xsum_cells(sv->xs), gsums);
+            if (gsums) cgh_xsum_groups_written(sv->xs);
             // ... and the launch of the sums of r may take x += alpha p along (xsum.hip, xs_fused): then K3 only updates p
             bool x_done = false;
             rc = strict_sums(sv, dr, dr, dr, 2, iter, s, sv->xs != nullptr, d_x, dp, &x_done);

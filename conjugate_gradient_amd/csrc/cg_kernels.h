@@ -85,10 +85,11 @@ __global__ __launch_bounds__(CGH_BLOCK) void cg_update_r(int64_t n, double *__re
                                                         const double *__restrict__ pAp_partials, int pAp_count,
                                                         double *__restrict__ out_partials, double *hist, int iter,
                                                         const int *__restrict__ done, int rev, const double *__restrict__ gs,
-                                                        double *__restrict__ cellsum = nullptr, int64_t ncells = 0)
+                                                        double *__restrict__ cellsum = nullptr, int64_t ncells = 0,
+                                                        double *__restrict__ groupsum = nullptr)
 {
     constexpr bool STRICT = MODE == 1;
-    __shared__ double lds[4];
+    __shared__ double lds[8];
     if (*done != 0) {
         // frozen.  A replayed (graph) launch tells the cg_update_xp behind it that there is no iteration in flight.
         if (iter == 0 && blockIdx.x == 0 && threadIdx.x == 0) const_cast<int *>(done)[1] = 0;
@@ -113,6 +114,51 @@ __global__ __launch_bounds__(CGH_BLOCK) void cg_update_r(int64_t n, double *__re
     double       rr = 0.0, l1 = 0.0;
     const int64_t pairs = n >> 1;
     const int64_t chunks = (pairs + CGH_BLOCK - 1) / CGH_BLOCK;
+    if constexpr (STRICT) {
+        if (cellsum != nullptr && groupsum != nullptr) {
+            // Strict mode with the order-exact sums (xsum.hip): a workgroup takes whole GROUPS of their hierarchy (64 cells =
+            // 8192 rows = 16 chunks, one after the other) and leaves, beside every cell's approximate r.r and |r|_1, the
+            // group's -- the sums' launch then needs no pass of its own over the cell sums (xs_group_sums).
+            const int64_t ngroups = (ncells + 63) / 64;
+            const int     wave = threadIdx.x >> 6;
+            for (int64_t g = blockIdx.x; g < ngroups; g += gridDim.x) {
+                double gq = 0.0, ga = 0.0;
+#pragma unroll 4
+                for (int c16 = 0; c16 < 16; ++c16) {
+                    const int64_t k = (g * 16 + c16) * CGH_BLOCK + threadIdx.x;
+                    double2       rn = make_double2(0.0, 0.0);
+                    if (k < pairs) {
+                        const double2 rv = ld2<VV>(r, k);
+                        const double2 av = ld2<VV>(Ap, k);
+                        rn = make_double2(madd_rn(rv.x, nalpha, av.x), madd_rn(rv.y, nalpha, av.y));
+                        st2<(VV & 4) != 0>(r, k, rn.x, rn.y);
+                    }
+                    const double  q = wave_sum_lane63(rn.x * rn.x + rn.y * rn.y), a = wave_sum_lane63(fabs(rn.x) + fabs(rn.y));
+                    const int64_t cell = k >> 6;
+                    if ((threadIdx.x & 63) == 63) {
+                        if (cell < ncells) {
+                            cellsum[cell] = q;
+                            cellsum[ncells + cell] = a;
+                        }
+                        gq += q;
+                        ga += a;
+                    }
+                }
+                if ((threadIdx.x & 63) == 63) {
+                    lds[wave] = gq;
+                    lds[4 + wave] = ga;
+                }
+                __syncthreads();
+                if (threadIdx.x == 0) {
+                    groupsum[g] = ((lds[0] + lds[1]) + lds[2]) + lds[3];
+                    groupsum[ngroups + g] = ((lds[4] + lds[5]) + lds[6]) + lds[7];
+                }
+                __syncthreads();
+            }
+            if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) r[n - 1] = madd_rn(r[n - 1], nalpha, Ap[n - 1]);
+            return;
+        }
+    }
     for (int64_t cc = blockIdx.x; cc < chunks; cc += gridDim.x) {
         const int64_t k = (rev ? chunks - 1 - cc : cc) * CGH_BLOCK + threadIdx.x;
         double2       rn = make_double2(0.0, 0.0);

@@ -206,6 +206,8 @@ int cgh_xsum_launch_part(cgh_xsum *w, int64_t n, const double *a, const double *
                          double *s_out, const int *done, hipStream_t s, bool presummed);
 int cgh_xsum_finalize(const double *sums, int mode, double *hist, int iter, double tol, int *done, hipStream_t s);
 double *cgh_xsum_cellsums(cgh_xsum *w);
+double *cgh_xsum_groupsums(cgh_xsum *w);       // [2][groups of 64 cells]: a producer may leave them too ...
+void    cgh_xsum_groups_written(cgh_xsum *w);   // ... and says so before the launch that consumes them
 int64_t cgh_xsum_cells(const cgh_xsum *w);
 
 // p2p.hip -- scalar all-reduce over peer stores (multi-GPU path); W-interleaved partials in, W sums out

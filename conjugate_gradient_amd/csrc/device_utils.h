@@ -19,6 +19,27 @@ __device__ __forceinline__ double wave_sum(double v)
     return v;
 }
 
+// The same with DPP moves only (no LDS crossbar round trips): prefix inside each row of 16 lanes, then the row totals
+// handed on (row_bcast:15, row_bcast:31).  Result valid in lane 63.  For the kernels that reduce once per 128 rows
+// (the per-cell sums that predict the binades of the order-exact sums, xsum.hip): any order will do there.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_mov_f64(double v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_sum_lane63(double v)
+{
+    v += dpp_mov_f64<0x111, 0xf>(v);  // row_shr:1 (lanes without a source lane add +0.0)
+    v += dpp_mov_f64<0x112, 0xf>(v);
+    v += dpp_mov_f64<0x114, 0xf>(v);
+    v += dpp_mov_f64<0x118, 0xf>(v);
+    v += dpp_mov_f64<0x142, 0xa>(v);  // row_bcast:15 into rows 1 and 3
+    v += dpp_mov_f64<0x143, 0xc>(v);  // row_bcast:31 into rows 2 and 3
+    return v;
+}
+
 // Sum over a 256-thread workgroup; result valid in thread 0.  `lds` holds >= 4 doubles.
 // The order (lane tree, then waves 0..3 left to right) is fixed, so the result is
 // run-to-run deterministic for a fixed launch shape.

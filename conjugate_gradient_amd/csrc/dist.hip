@@ -1214,6 +1214,40 @@ int cgh_dist_iterate(cgh_dist *d, int count, int time_kernels)
     return CGH_OK;
 }
 
+// Launcher diagnostic: `reps` all-reduces of two doubles back to back on the compute stream, through the transport named
+// (1 = the peer-to-peer mailboxes of p2p.hip as a kernel of its own, 0 = ncclAllReduce), timed with HIP events around the
+// whole loop: microseconds per exchange as the slowest-to-arrive rank sees them.  Collective: every rank calls it with
+// the same arguments.
+int cgh_comm_bench_allreduce(int reps, int use_p2p, double *us_per_exchange)
+{
+    CGH_REQUIRE_READY(CGH_ENODEV);
+    if (reps < 1 || !us_per_exchange) return CGH_EINVAL;
+    if (use_p2p ? !cgh_p2p_connected() : (g_rccl.comm == nullptr)) {
+        cgh_set_error("cgh_comm_bench_allreduce: that transport is not up");
+        return CGH_ECOMM;
+    }
+    hipStream_t s = g_cgh.stream;
+    double     *buf = (double *)cgh_alloc(sizeof(double) * 8);
+    if (!buf) return CGH_ENOMEM;
+    hipEvent_t a = nullptr, b = nullptr;
+    int        rc = CGH_OK;
+    const double v[2] = {1.0, -0.5};
+    if (cgh_h2d(buf, v, sizeof v) != CGH_OK || hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) rc = CGH_EHIP;
+    for (int k = -8; rc == CGH_OK && k < reps; ++k) {  // (8 untimed exchanges first)
+        if (k == 0 && hipEventRecord(a, s) != hipSuccess) rc = CGH_EHIP;
+        if (use_p2p) rc = rc ? rc : cgh_p2p_launch(2, buf, 1, buf + 2, s);
+        else if (g_rccl.AllReduce(buf, buf + 2, 2, ncclDouble, ncclSum, g_rccl.comm, s) != ncclSuccess) rc = CGH_ECOMM;
+    }
+    float ms = 0.f;
+    if (rc == CGH_OK && (hipEventRecord(b, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess || hipEventElapsedTime(&ms, a, b) != hipSuccess))
+        rc = CGH_EHIP;
+    if (a) (void)hipEventDestroy(a);
+    if (b) (void)hipEventDestroy(b);
+    cgh_free(buf);
+    if (rc == CGH_OK) *us_per_exchange = (double)ms * 1e3 / reps;
+    return rc;
+}
+
 int cgh_dist_poll(cgh_dist *d, int *done_iter, int *queued)
 {
     CGH_REQUIRE_READY(CGH_ENODEV);

@@ -195,8 +195,8 @@ __global__ __launch_bounds__(CGH_BLOCK) void spmv_ell_r2(int64_t n, int Krt, con
         if constexpr (DOT == 2) {
             // strict mode: a wave's 64 row pairs are one 128-row cell of the order-exact sums (xsum.hip); its approximate
             // x.y goes to partials[cell].  Launched only for one full range with n % 128 == 0: every wave is full or idle.
-            const double q = wave_sum(xi.x * a0 + xi.y * a1);
-            if ((threadIdx.x & 63) == 0) partials[pr >> 6] = q;
+            const double q = wave_sum_lane63(xi.x * a0 + xi.y * a1);
+            if ((threadIdx.x & 63) == 63) partials[pr >> 6] = q;
         }
     }
     if constexpr (DOT == 1) {

@@ -30,7 +30,9 @@ struct cgh_xsum {
     double     *xfer = nullptr;      // [4]: the two sums on their way to the finalising workgroup, its ticket
     unsigned   *ready = nullptr;     // [2][batches of 64 groups]: groups summarised so far in the running fused launch (zero between launches)
     xs_summary *batches = nullptr;   // [2][batches]: the join of each batch's group summaries (fused launch)
+    unsigned   *head = nullptr;      // [2]: workgroups of the head group counted so far (fused launch, group level; zero between launches)
     bool        owns = true;         // false: object and arrays live in storage of the caller's (cgh_xsum_place)
+    bool        groups_presummed = false;  // the producer of the vector also left the group sums (consumed by the next launch)
 };
 
 namespace {
@@ -186,20 +188,54 @@ __device__ __forceinline__ int64_t shfl_down_i64(int64_t v, int off) { return (i
 __device__ __forceinline__ int64_t shfl_up_i64(int64_t v, int off) { return (int64_t)__shfl_up((long long)v, off, 64); }
 __device__ __forceinline__ int64_t shfl_i64(int64_t v, int src) { return (int64_t)__shfl((long long)v, src, 64); }
 
-// join over the 64 lanes (lane order = run order); result valid in lane 0
+// 64-bit / 32-bit DPP moves inside a row of 16 lanes (no LDS crossbar round trips)
+template <int CTRL>
+__device__ __forceinline__ int64_t row_dpp_i64(int64_t v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)v, CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(v >> 32), CTRL, 0xf, 0xf, false);
+    return (int64_t)(((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo);
+}
+template <int CTRL>
+__device__ __forceinline__ int row_dpp_i32(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false); }
+__device__ __forceinline__ int64_t readlane_i64_early(int64_t v, int k)
+{
+    const int lo = __builtin_amdgcn_readlane((int)(uint32_t)v, k), hi = __builtin_amdgcn_readlane((int)(v >> 32), k);
+    return (int64_t)(((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo);
+}
+
+// join over the 64 lanes (lane order = run order); result valid in lane 0.  Inside each row of 16 lanes a tree of DPP
+// moves (lane i takes lane i + off of its row), then the four row summaries are read out of lanes 16, 32, 48 and joined
+// left to right: no LDS round trip anywhere (the shuffle tree over 64 lanes cost 72 ds_bpermutes per join).
 __device__ __forceinline__ xs_summary wave_join(xs_summary q)
 {
+    const int sub = threadIdx.x & 15;
+#define XS_JOIN_STEP(CTRL, OFF)                       \
+    {                                                 \
+        xs_summary o;                                 \
+        o.A = row_dpp_i64<CTRL>(q.A);                 \
+        o.C = row_dpp_i64<CTRL>(q.C);                 \
+        o.Mlo = row_dpp_i64<CTRL>(q.Mlo);             \
+        o.Mhi = row_dpp_i64<CTRL>(q.Mhi);             \
+        o.E = row_dpp_i32<CTRL>(q.E);                 \
+        o.meta = row_dpp_i32<CTRL>(q.meta);           \
+        if (sub + OFF < 16) q = xs_join(q, o);        \
+    }
+    XS_JOIN_STEP(0x101, 1)  // row_shl:1
+    XS_JOIN_STEP(0x102, 2)
+    XS_JOIN_STEP(0x104, 4)
+    XS_JOIN_STEP(0x108, 8)
+#undef XS_JOIN_STEP
 #pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
+    for (int row = 1; row < 4; ++row) {
         xs_summary o;
-        o.A = shfl_down_i64(q.A, off);
-        o.C = shfl_down_i64(q.C, off);
-        o.Mlo = shfl_down_i64(q.Mlo, off);
-        o.Mhi = shfl_down_i64(q.Mhi, off);
-        o.E = __shfl_down(q.E, off, 64);
-        o.meta = __shfl_down(q.meta, off, 64);
-        // lanes whose partner is beyond the wave keep their own (their value is not used by lane 0's tree)
-        if ((int)(threadIdx.x & 63) + off < 64) q = xs_join(q, o);
+        o.A = readlane_i64_early(q.A, 16 * row);
+        o.C = readlane_i64_early(q.C, 16 * row);
+        o.Mlo = readlane_i64_early(q.Mlo, 16 * row);
+        o.Mhi = readlane_i64_early(q.Mhi, 16 * row);
+        o.E = __builtin_amdgcn_readlane(q.E, 16 * row);
+        o.meta = __builtin_amdgcn_readlane(q.meta, 16 * row);
+        if ((threadIdx.x & 63) == 0) q = xs_join(q, o);  // (only lane 0 carries the running join: lanes 16, 32, 48 keep their rows')
     }
     return q;
 }
@@ -241,97 +277,128 @@ __device__ __forceinline__ int64_t row_max(int64_t v)
 // is exactly one.  Two builds: rolled loops and out of line for the streaming kernel (the rare path must not set the
 // register budget of the kernel that holds it), unrolled and inline for sums of a few hundred cells, where one workgroup's
 // latency is the kernel's and a good part of the cells is flagged (the head of a sum, one crossing per doubling).
-template <int UNR>
-__device__ __forceinline__ xs_summary xs_cell16_exact_impl(const double *tl, int32_t E, int32_t neg, int64_t Mt)
+// 64-bit DPP moves inside a row of 16 lanes (no LDS crossbar round trips: the exact routine used to spend most of its
+// ~13 us in 75 ds_bpermutes and in classifying every element five times)
+// exclusive prefix over the row's lanes (row_shr: lanes without a source lane receive 0)
+__device__ __forceinline__ int64_t row_excl_scan_dpp(int64_t v)
 {
-    double t[8];
+    int64_t incl = v;
+    incl += row_dpp_i64<0x111>(incl);
+    incl += row_dpp_i64<0x112>(incl);
+    incl += row_dpp_i64<0x114>(incl);
+    incl += row_dpp_i64<0x118>(incl);
+    return incl - v;
+}
+// min / max over the row, in every lane (row_ror: every lane has a source lane)
+__device__ __forceinline__ int64_t row_min_dpp(int64_t v)
+{
+    int64_t o;
+    o = row_dpp_i64<0x121>(v); v = o < v ? o : v;
+    o = row_dpp_i64<0x122>(v); v = o < v ? o : v;
+    o = row_dpp_i64<0x124>(v); v = o < v ? o : v;
+    o = row_dpp_i64<0x128>(v); v = o < v ? o : v;
+    return v;
+}
+__device__ __forceinline__ int64_t row_max_dpp(int64_t v)
+{
+    int64_t o;
+    o = row_dpp_i64<0x121>(v); v = o > v ? o : v;
+    o = row_dpp_i64<0x122>(v); v = o > v ? o : v;
+    o = row_dpp_i64<0x124>(v); v = o > v ? o : v;
+    o = row_dpp_i64<0x128>(v); v = o > v ? o : v;
+    return v;
+}
+
+// op: what the LDS rows hold -- 0 the terms themselves, 1 the operand whose SQUARE is the term (r.r), 2 the operand whose
+// absolute value is the term (|r|_1): the sums of r keep ONE copy of r in LDS for both.
+__device__ __forceinline__ double xs_term_of(double w, int op) { return op == 1 ? mul_rn(w, w) : op == 2 ? fabs(w) : w; }
+
+// Same result as xs_cell_summary (xsum.h) on the cell's 128 elements.  Every element is classified ONCE under the
+// assumed binade E (movement and class kept in registers) and the elements behind the special one once more under the
+// binade it leaves the sum in; the row scans are DPP moves.
+__device__ __forceinline__ xs_summary xs_cell16_exact_impl(const double *tl, int32_t E, int32_t neg, int64_t Mt, int op)
+{
+    double  t[8];
+    int64_t dk[8];
+    int     cls8 = 0;  // 2 bits per element
 #pragma unroll
-    for (int k = 0; k < 8; ++k) t[k] = tl[k];  // (UNR == 1: the compiler leaves them in LDS)
+    for (int k = 0; k < 8; ++k) t[k] = xs_term_of(tl[k], op);
     const int lane = threadIdx.x & 63, sub = lane & 15, row0 = lane & 48;
-    int64_t   T = 0, dk, lo_l = 0, hi_l = 0;
-    bool      hard = false, tie = false;
-#pragma unroll UNR
+    int64_t   T = 0, lo_l = 0, hi_l = 0;
+#pragma unroll
     for (int k = 0; k < 8; ++k) {
-        const int cls = xs_classify(t[k], E, neg, &dk);
-        hard = hard || cls == 2;
-        tie = tie || cls == 1;
-        T += cls ? 0 : dk;
+        const int cls = xs_classify(t[k], E, neg, &dk[k]);
+        cls8 |= cls << (2 * k);
+        if (cls) dk[k] = 0;  // (a tie's floor is recomputed where it is needed)
+        T += dk[k];
         lo_l = T < lo_l ? T : lo_l;
         hi_l = T > hi_l ? T : hi_l;
     }
-    const int64_t base = row_excl_scan(T, sub);
+    const bool    hard = (cls8 & 0xaaaa) != 0, tie = (cls8 & 0x5555) != 0;
+    const int64_t base = row_excl_scan_dpp(T);
     int           kx = 8, ty = 0;
     int64_t       run = base;
-#pragma unroll UNR
+#pragma unroll
     for (int k = 0; k < 8; ++k) {
-        const int cls = xs_classify(t[k], E, neg, &dk);
+        const int cls = (cls8 >> (2 * k)) & 3;
         if (kx == 8 && cls == 1) {
             kx = k;
             ty = 1;
-        } else if (kx == 8 && cls == 0 && Mt + run + dk > XS_TWO53 - 2) {
+        } else if (kx == 8 && cls == 0 && Mt + run + dk[k] > XS_TWO53 - 2) {
             kx = k;
             ty = 2;
         }
-        run += cls ? 0 : dk;
+        run += dk[k];
     }
     const unsigned hard_row = (unsigned)(__ballot(hard) >> row0) & 0xffffu, tie_row = (unsigned)(__ballot(tie) >> row0) & 0xffffu;
     const unsigned spec_row = (unsigned)(__ballot(kx < 8) >> row0) & 0xffffu;
     bool           valid = !hard_row && spec_row;
     // the plain summary: what the cell is if it has no (single) special element
-    const xs_summary plain = xs_regular(shfl_i64(base + T, row0 + 15), row_min(base + lo_l), row_max(base + hi_l), E, neg,
+    const xs_summary plain = xs_regular(shfl_i64(base + T, row0 + 15), row_min_dpp(base + lo_l), row_max_dpp(base + hi_l), E, neg,
                                         hard_row || tie_row);
     const int      lstar = spec_row ? (int)__builtin_ctz(spec_row) : 0, src = row0 + lstar;
     const int      kstar = __shfl(kx, src, 64), type = __shfl(ty, src, 64);
-    // part 1: everything before the special element, in binade E
+    // part 1: everything before the special element, in binade E (nothing before the first special element is one)
     int64_t lo1 = 0, hi1 = 0;
     run = base;
-#pragma unroll UNR
+#pragma unroll
     for (int k = 0; k < 8; ++k)
         if (sub < lstar || (sub == lstar && k < kstar)) {
-            xs_classify(t[k], E, neg, &dk);  // (nothing before the first special element is one)
-            run += dk;
+            run += dk[k];
             lo1 = run < lo1 ? run : lo1;
             hi1 = run > hi1 ? run : hi1;
         }
     const int64_t P = shfl_i64(run, src);
-    lo1 = row_min(lo1);
-    hi1 = row_max(hi1);
+    lo1 = row_min_dpp(lo1);
+    hi1 = row_max_dpp(hi1);
     // the special element
     double ts = 0.0;
-    if constexpr (UNR == 1) {
-        ts = tl[kstar & 7];
-    } else {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) ts = k == kstar ? t[k] : ts;
-    }
+    for (int k = 0; k < 8; ++k) ts = k == kstar ? t[k] : ts;
     const double  tau = ldexp(neg ? -ts : ts, 1075 - E), cfl = floor(tau);
     const int64_t c = shfl_i64((int64_t)cfl, src);
     const int     whole = __shfl((int)(tau == cfl), src, 64);
     if (type == 2 && whole) valid = false;  // integer tau at a crossing: a tie in the new binade when W + c is odd
     // part 2: everything after it, in the binade it leaves the sum in
     const int32_t E2 = type == 2 ? E + 1 : E;
-    int64_t       T2 = 0;
+    int64_t       T2 = 0, lo2 = 0, hi2 = 0;
     bool          bad2 = false;
-#pragma unroll UNR
+#pragma unroll
     for (int k = 0; k < 8; ++k)
         if (sub > lstar || (sub == lstar && k > kstar)) {
-            if (xs_classify(t[k], E2, neg, &dk)) bad2 = true, dk = 0;
-            T2 += dk;
+            int64_t d2;
+            if (xs_classify(t[k], E2, neg, &d2)) bad2 = true, d2 = 0;
+            T2 += d2;
+            lo2 = T2 < lo2 ? T2 : lo2;   // (relative to the lane's own start: base2 is added below)
+            hi2 = T2 > hi2 ? T2 : hi2;
         }
-    const int64_t base2 = row_excl_scan(T2, sub);
+    const int64_t base2 = row_excl_scan_dpp(T2);
     const int64_t D2 = shfl_i64(base2 + T2, row0 + 15);
-    int64_t       lo2 = 0, hi2 = 0;
-    run = base2;
-#pragma unroll UNR
-    for (int k = 0; k < 8; ++k)
-        if (sub > lstar || (sub == lstar && k > kstar)) {
-            if (xs_classify(t[k], E2, neg, &dk)) dk = 0;
-            run += dk;
-            lo2 = run < lo2 ? run : lo2;
-            hi2 = run > hi2 ? run : hi2;
-        }
-    lo2 = row_min(lo2);
-    hi2 = row_max(hi2);
+    // prefixes inside a lane start at base2: min over (base2 + prefix) with the empty prefix 0 of the whole part included
+    lo2 = row_min_dpp(sub >= lstar ? base2 + lo2 : 0);
+    hi2 = row_max_dpp(sub >= lstar ? base2 + hi2 : 0);
+    lo2 = lo2 < 0 ? lo2 : 0;
+    hi2 = hi2 > 0 ? hi2 : 0;
     if ((unsigned)(__ballot(bad2) >> row0) & 0xffffu) valid = false;  // a second special element
     if (!valid) return plain;
     return type == 2 ? xs_crossing(P, lo1, hi1, c, D2, lo2, hi2, E, neg, false) : xs_tie(P, lo1, hi1, c, D2, lo2, hi2, E, neg, false);
@@ -399,9 +466,9 @@ __device__ __forceinline__ unsigned long long readlane_words(const xs_summary &q
     return r;
 }
 
-__device__ __noinline__ xs_summary xs_cell16_exact(const double *t, int32_t E, int32_t neg, int64_t Mt)
+__device__ __noinline__ xs_summary xs_cell16_exact(const double *t, int32_t E, int32_t neg, int64_t Mt, int op)
 {
-    return xs_cell16_exact_impl<1>(t, E, neg, Mt);
+    return xs_cell16_exact_impl(t, E, neg, Mt, op);
 }
 
 // One workgroup per group.  16 lanes share a cell (8 consecutive elements each: a short serial prefix in registers,
@@ -418,27 +485,34 @@ struct xsm_shared {
 // `bid` = the workgroup's number among those that summarise.  FUSED: the driver runs in the same launch (xs_fused): the
 // summaries are written through to memory and the group is counted in ready[slot][batch of the group].
 template <int KIND, bool FLAT, bool FUSED>
-__device__ __forceinline__ void xs_summarize_body(xsm_shared<(KIND == XS_BOTH_SAME ? 2 : 1)> &W, const unsigned bid, int64_t n,
+__device__ __forceinline__ void xs_summarize_body(xsm_shared<1> &W, const unsigned bid, int64_t n,
                                                   const double *__restrict__ a, const double *__restrict__ b,
                                                   const double *__restrict__ c, int64_t ncells, int64_t ngroups,
                                                   const double *__restrict__ cellsum, const double *__restrict__ groupsum,
                                                   const double *__restrict__ gprefix, xs_summary *__restrict__ cells,
                                                   xs_summary *__restrict__ groups, const double *__restrict__ offsets,
-                                                  unsigned *__restrict__ ready, xs_summary *__restrict__ batches, int64_t nbatch)
+                                                  unsigned *__restrict__ ready, xs_summary *__restrict__ batches, int64_t nbatch,
+                                                  const int head_pass = -1, unsigned *__restrict__ head_count = nullptr)
 {
     constexpr int S0 = KIND == XS_L1 ? 1 : 0, S1 = KIND == XS_DOT ? 0 : 1;  // slots in use: S0..S1
     auto &start = W.start;
     auto &sm = W.sm;
     auto &red = W.red;
     auto &tr = W.tr;
-    constexpr int XS_TR = 4 * 64 * 10;  // doubles per slot
+    // the sums of r (r.r and |r|_1 at once) transpose r ITSELF through LDS, once, and form both terms after the transposition
+    constexpr bool RAW = KIND == XS_BOTH_SAME;
     const int     lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // groups == NULL ("flat", few cells): four workgroups per group, one pass of 16 cells each, no group summary --
     // the whole problem is then a handful of workgroups, and their serial depth is what counts
     constexpr bool flat = FLAT;  // (groups == NULL)
-    const int64_t g = flat ? bid >> 2 : bid;
+    // head_pass >= 0 (fused launch, group level): this is one of the FOUR workgroups that share group 0, one pass each.
+    // The head of a sum is where the running sum doubles every few elements: several of group 0's cells take the exact
+    // integer routine, a workgroup that runs the four passes one after the other needs 35 us for them where the others
+    // need 15 (tools/trace_wgs.py) -- and the walk can only start once group 0 is in.
+    const bool    head = !flat && head_pass >= 0;
+    const int64_t g = flat ? bid >> 2 : (head ? 0 : bid);
     const int sub = threadIdx.x & 15;  // position inside the cell's 16 lanes
-    const int pass_lo = flat ? (int)(bid & 3) : 0, pass_hi = flat ? pass_lo + 1 : 4;
+    const int pass_lo = flat ? (int)(bid & 3) : (head ? head_pass : 0), pass_hi = flat || head ? pass_lo + 1 : 4;
     // Loads are coalesced -- load j of a lane fetches elements 32 j + 2 sub, + 1 of its cell, so 16 lanes read 256
     // contiguous bytes (8 consecutive elements per lane, the layout the scan wants, made every load touch 64 different
     // lines: 3.8 TB/s at best) -- and the terms go through LDS to reach the lane that scans them: lane r of the cell owns
@@ -485,24 +559,32 @@ __device__ __forceinline__ void xs_summarize_body(xsm_shared<(KIND == XS_BOTH_SA
         __builtin_amdgcn_wave_barrier();  // the previous pass's reads of the rows are over
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            double d[2], l[2];
-            xs_raw_terms<KIND>(u[j], v[j], d, l);
             double *dst = mine + (4 * j + (sub >> 2)) * 10 + 2 * (sub & 3);
-            if constexpr (S0 == 0) *reinterpret_cast<double2 *>(dst) = make_double2(d[0], d[1]);
-            if constexpr (S1 == 1) *reinterpret_cast<double2 *>(dst + (S1 - S0) * XS_TR) = make_double2(l[0], l[1]);
+            if constexpr (RAW) {
+                *reinterpret_cast<double2 *>(dst) = u[j];
+            } else {
+                double d[2], l[2];
+                xs_raw_terms<KIND>(u[j], v[j], d, l);
+                *reinterpret_cast<double2 *>(dst) = S0 == 0 ? make_double2(d[0], d[1]) : make_double2(l[0], l[1]);
+            }
         }
         if (pass + 1 < pass_hi) fetch(pass + 1);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
-        for (int slot = S0; slot <= S1; ++slot)
-#pragma unroll
-            for (int k = 0; k < 8; k += 2) {
-                const double2 w = *reinterpret_cast<const double2 *>(mine + (slot - S0) * XS_TR + sub * 10 + k);
-                t[slot][k] = w.x;
-                t[slot][k + 1] = w.y;
+        for (int k = 0; k < 8; k += 2) {
+            const double2 w = *reinterpret_cast<const double2 *>(mine + sub * 10 + k);
+            if constexpr (RAW) {
+                t[0][k] = mul_rn(w.x, w.x);
+                t[0][k + 1] = mul_rn(w.y, w.y);
+                t[1][k] = fabs(w.x);
+                t[1][k + 1] = fabs(w.y);
+            } else {
+                t[S0][k] = w.x;
+                t[S0][k + 1] = w.y;
             }
+        }
 #pragma unroll
         for (int slot = S0; slot <= S1; ++slot) {
             int32_t    E, neg;
@@ -560,8 +642,9 @@ __device__ __forceinline__ void xs_summarize_body(xsm_shared<(KIND == XS_BOTH_SA
             const unsigned long long want_rows = __ballot(want && sub == 0);
             want = (want_rows >> (lane & 48)) & 1;
             if (want_rows) {  // whole waves enter; ~ln(n) ties and ~log2(n) crossings per sum, so almost none do
-                const double    *row = mine + (slot - S0) * XS_TR + sub * 10;
-                const xs_summary ex = FLAT ? xs_cell16_exact_impl<8>(row, E, neg, Mt) : xs_cell16_exact(row, E, neg, Mt);
+                const double    *row = mine + sub * 10;
+                const int        op = RAW ? (slot == 0 ? 1 : 2) : 0;
+                const xs_summary ex = FLAT ? xs_cell16_exact_impl(row, E, neg, Mt, op) : xs_cell16_exact(row, E, neg, Mt, op);
                 if (want) q = ex;
             }
             if (sub == 0) {
@@ -616,37 +699,69 @@ __device__ __forceinline__ void xs_summarize_body(xsm_shared<(KIND == XS_BOTH_SA
         // the group's summaries go into the start[] rows (dead since the passes), then the 64 cell summaries and the
         // group's are written through in one coalesced sweep
         xs_summary *gq = reinterpret_cast<xs_summary *>(&start[0][0]);  // [2] summaries in 1 KiB
-        if (wave >= S0 && wave <= S1) {
-            const xs_summary q = wave_join(sm[wave][lane]);
-            if (lane == 0) gq[wave] = q;
-        }
-        __syncthreads();
-        const int ccnt = (int)(ncells - g * XS_GROUP < XS_GROUP ? ncells - g * XS_GROUP : XS_GROUP);
+        int        *last = reinterpret_cast<int *>(&red[0]);            // (red: 4 doubles, dead by now) [0..1] head, [2..3] batch
+        if (!head) {
+            if (wave >= S0 && wave <= S1) {
+                const xs_summary q = wave_join(sm[wave][lane]);
+                if (lane == 0) gq[wave] = q;
+            }
+            __syncthreads();
+            const int ccnt = (int)(ncells - g * XS_GROUP < XS_GROUP ? ncells - g * XS_GROUP : XS_GROUP);
 #pragma unroll
-        for (int slot = S0; slot <= S1; ++slot) {
-            xs_store_words_agent(reinterpret_cast<unsigned long long *>(cells + slot * ncells + g * XS_GROUP),
-                                 reinterpret_cast<const unsigned long long *>(&sm[slot][0]), ccnt * 5);
-            if (threadIdx.x < 5)
-                __hip_atomic_store(reinterpret_cast<unsigned long long *>(groups + slot * ngroups + g) + threadIdx.x,
-                                   reinterpret_cast<const unsigned long long *>(gq + slot)[threadIdx.x], __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_AGENT);
+            for (int slot = S0; slot <= S1; ++slot) {
+                xs_store_words_agent(reinterpret_cast<unsigned long long *>(cells + slot * ncells + g * XS_GROUP),
+                                     reinterpret_cast<const unsigned long long *>(&sm[slot][0]), ccnt * 5);
+                if (threadIdx.x < 5)
+                    __hip_atomic_store(reinterpret_cast<unsigned long long *>(groups + slot * ngroups + g) + threadIdx.x,
+                                       reinterpret_cast<const unsigned long long *>(gq + slot)[threadIdx.x], __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+            }
+            xs_stores_acknowledged();  // every wave's write-through stores have been acknowledged by memory ...
+            __syncthreads();
+        } else {
+            // one of the four workgroups of group 0 (a full group: this path has more than 2048 cells): its 16 cell
+            // summaries go out; the last of the four reads all 64 back, joins them into the group's summary and goes on
+            // as the workgroup of a whole group does
+#pragma unroll
+            for (int slot = S0; slot <= S1; ++slot)
+                xs_store_words_agent(reinterpret_cast<unsigned long long *>(cells + slot * ncells + head_pass * 16),
+                                     reinterpret_cast<const unsigned long long *>(&sm[slot][head_pass * 16]), 16 * 5);
+            xs_stores_acknowledged();
+            __syncthreads();
+            if (threadIdx.x == 0) {
+#pragma unroll
+                for (int slot = S0; slot <= S1; ++slot) {
+                    const unsigned old = __hip_atomic_fetch_add(head_count + (slot - S0), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    last[slot] = old == 3u;
+                    if (old == 3u) __hip_atomic_store(head_count + (slot - S0), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // zero for the next launch
+                }
+            }
+            __syncthreads();
+            if (wave >= S0 && wave <= S1 && last[wave]) {
+                const xs_summary q = xs_load_agent(cells + wave * ncells + lane);
+                const xs_summary j = wave_join(q);
+                if (lane < 5)
+                    __hip_atomic_store(reinterpret_cast<unsigned long long *>(groups + wave * ngroups) + lane, readlane_words(j, lane),
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                xs_stores_acknowledged();  // (one wave: group 0's summary is in memory before the group is counted)
+            }
+            __syncthreads();
         }
-        xs_stores_acknowledged();  // every wave's write-through stores have been acknowledged by memory ...
-        __syncthreads();
-        int *last = reinterpret_cast<int *>(&red[0]);            // (red: 4 doubles, dead by now)
         const int64_t bb = g >> 6;
         const int     gcnt = (int)(ngroups - bb * 64 < 64 ? ngroups - bb * 64 : 64);
         if (threadIdx.x == 0) {                                  // ... before the group is counted
 #pragma unroll
             for (int slot = S0; slot <= S1; ++slot) {
+                last[2 + slot] = 0;
+                if (head && !last[slot]) continue;               // (group 0 is counted by the last of its four workgroups)
                 const unsigned old = __hip_atomic_fetch_add(ready + (slot - S0) * nbatch + bb, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                last[slot] = old == (unsigned)(gcnt - 1);
+                last[2 + slot] = old == (unsigned)(gcnt - 1);
             }
         }
         __syncthreads();
         // The workgroup that completes a batch of 64 groups joins their summaries into the batch's (they are all in memory:
         // every group was written through before it was counted) and raises the batch's flag for the driver.
-        if (wave >= S0 && wave <= S1 && last[wave]) {
+        if (wave >= S0 && wave <= S1 && last[2 + wave]) {
             xs_summary q = xs_identity();
             if (lane < gcnt) q = xs_load_agent(groups + wave * ngroups + bb * 64 + lane);
             const xs_summary j = wave_join(q);
@@ -667,7 +782,7 @@ __global__ __launch_bounds__(256) void xs_summarize(int64_t n, const double *__r
                                                    const double *__restrict__ gprefix, xs_summary *__restrict__ cells,
                                                    xs_summary *__restrict__ groups, const double *__restrict__ offsets)
 {
-    __shared__ xsm_shared<(KIND == XS_BOTH_SAME ? 2 : 1)> W;
+    __shared__ xsm_shared<1> W;
     xs_summarize_body<KIND, FLAT, false>(W, blockIdx.x, n, a, b, c, ncells, ngroups, cellsum, groupsum, gprefix, cells, groups, offsets,
                                          nullptr, nullptr, 0);
 }
@@ -1288,38 +1403,58 @@ __global__ __launch_bounds__(256) void xs_fused(int64_t n, const double *__restr
                                                const double *__restrict__ gprefix, xs_summary *__restrict__ cells,
                                                xs_summary *__restrict__ groups, xs_summary *__restrict__ batches,
                                                unsigned *__restrict__ ready, int mode, double *hist, int iter, double tol, int *done,
-                                               double *out, double *xfer, long long *trace, double *xu_x, const double *xu_p)
+                                               double *out, double *xfer, long long *trace, double *xu_x, const double *xu_p,
+                                               long long *wgtrace, unsigned *__restrict__ head_count)
 {
     constexpr int S0 = KIND == XS_L1 ? 1 : 0, S1 = KIND == XS_DOT ? 0 : 1, ND = S1 - S0 + 1;
-    typedef xsm_shared<ND> sum_shared;
+    typedef xsm_shared<1> sum_shared;
+    // optional stamps of every workgroup (tools/trace_wgs.py): [4 b] start, [4 b + 1] end, 100 MHz ticks; [4 b + 2] its role
+    if (wgtrace != nullptr && threadIdx.x == 0) wgtrace[4 * (size_t)blockIdx.x] = wall_clock64();
+    struct stamp_end {
+        long long *p;
+        __device__ ~stamp_end()
+        {
+            if (p != nullptr && threadIdx.x == 0) p[1] = wall_clock64();
+        }
+    } stamp{wgtrace != nullptr ? wgtrace + 4 * (size_t)blockIdx.x : nullptr};
     constexpr size_t       LDS = sizeof(sum_shared) > sizeof(xr_shared) ? sizeof(sum_shared) : sizeof(xr_shared);
     __shared__ __attribute__((aligned(16))) unsigned char raw[LDS];
     // Drivers and summarising workgroups of one launch all take the same side: the flag only changes when a driver
-    // finalises, after the last summary of the launch.  The workgroups that only carry x += alpha p are not waited for by
-    // anyone: one that starts after the driver has finalised a CONVERGING iteration finds the flag naming this very
-    // iteration and still owes its rows their update (as cg_update_xp: frozen means an EARLIER iteration converged).
+    // finalises, after the last summary of the launch (the workgroups that only carry x += alpha p: see below).
     const int frozen_at = done != nullptr && mode != 3 && mode != 0 ? *done : 0;
     const int64_t nbatch = FLAT ? ngroups : (ngroups + 63) / 64;
     if (blockIdx.x >= (unsigned)ND) {
         unsigned sb = blockIdx.x - ND;  // the workgroup's number among those that are no drivers
         if constexpr (KIND == XS_BOTH_SAME && !FLAT) {
-            // The summaries of r.r and |r|_1 are bound by their arithmetic (134 MB in 65 us), so the launch also carries the
-            // x += alpha p of the same CG iteration (cg.c:467 of the reference), which is pure bandwidth: every fifth
-            // workgroup updates the x of four groups' rows instead of summarising (cg_update_xp then leaves x alone).
+            // The summaries of r.r and |r|_1 are bound by their arithmetic, so the launch also carries the x += alpha p of the
+            // same CG iteration (cg.c:467 of the reference), which is pure bandwidth: every fifth workgroup updates the x of
+            // four groups' rows instead of summarising (cg_update_xp then leaves x alone).  Tried in round 3 and dropped: one
+            // x workgroup per group (129 us for the launch instead of 104: twice the workgroup slots), and the x update at
+            // the tail of every summarising workgroup (109 us).
             if (xu_x != nullptr) {
                 const unsigned k = sb / 5, r = sb % 5;
                 if (r == 4) {
+                    if (wgtrace != nullptr && threadIdx.x == 0) wgtrace[4 * (size_t)blockIdx.x + 2] = 2;  // x update
+                    // nobody waits for these workgroups: one that starts after the driver has finalised a CONVERGING
+                    // iteration finds the flag naming this very iteration and still owes its rows their update
                     const int it = iter ? iter : done[1];  // (replayed launches: the iteration number comes from the device)
                     if (frozen_at == 0 || frozen_at == it) xs_update_x(n, xu_x, xu_p, hist, it, done, k);
                     return;
                 }
                 sb = k * 4 + r;
-                if ((int64_t)sb >= ngroups) return;
             }
         }
         if (frozen_at != 0) return;
-        xs_summarize_body<KIND, FLAT, true>(*reinterpret_cast<sum_shared *>(raw), sb, n, a, b, c, ncells, ngroups, cellsum, groupsum, gprefix,
-                                             cells, groups, nullptr, ready, batches, nbatch);
+        if constexpr (FLAT) {
+            xs_summarize_body<KIND, FLAT, true>(*reinterpret_cast<sum_shared *>(raw), sb, n, a, b, c, ncells, ngroups, cellsum, groupsum,
+                                                 gprefix, cells, groups, nullptr, ready, batches, nbatch);
+        } else {
+            // group level: summarising workgroups 0..3 share group 0 (one pass each), workgroup s >= 4 takes group s - 3
+            if ((int64_t)sb >= ngroups + 3) return;
+            xs_summarize_body<KIND, FLAT, true>(*reinterpret_cast<sum_shared *>(raw), sb < 4 ? 0u : sb - 3u, n, a, b, c, ncells, ngroups, cellsum,
+                                                 groupsum, gprefix, cells, groups, nullptr, ready, batches, nbatch, sb < 4 ? (int)sb : -1,
+                                                 head_count);
+        }
         return;
     }
     if (frozen_at != 0) return;
@@ -1357,6 +1492,7 @@ __global__ void xs_finalize_kernel(const double *__restrict__ sums, int mode, do
     if (!frozen) xs_finalize(sums[0], sums[1], mode, hist, iter, tol, done, nullptr);
 }
 
+long long *g_xs_wgtrace = nullptr;  // device buffer of 4 words per workgroup of a fused launch, or NULL (cgh_xsum_set_wgtrace)
 long long *g_xs_prof = nullptr;  // device buffer of 16 words, or NULL (cgh_xsum_set_prof)
 long long *g_xs_trace = nullptr; // device buffer of 224 words, or NULL (cgh_xsum_set_trace): time stamps of the fused driver
 
@@ -1368,8 +1504,14 @@ int launch_all(cgh_xsum *w, bool presummed, int64_t n, const double *a, const do
     if (xu_taken) *xu_taken = false;
     const unsigned ng = (unsigned)w->ngroups;
     const double *gsum = w->groupsum;
+    struct consume {
+        cgh_xsum *w;
+        ~consume() { w->groups_presummed = false; }
+    } consume_flag{w};
     if (presummed && w->ncells <= 4096) {
         gsum = nullptr;  // every workgroup of xs_summarize adds up the cell sums before its group itself: no launch here
+    } else if (presummed && w->groups_presummed) {
+        // (cg_update_r left the group sums beside the cell sums: nothing to launch)
     } else if (presummed) {
         constexpr int S0 = KIND == XS_L1 ? 1 : 0, S1 = KIND == XS_DOT ? 0 : 1;
         const int64_t waves = (int64_t)(S1 - S0 + 1) * w->ngroups;
@@ -1395,11 +1537,11 @@ int launch_all(cgh_xsum *w, bool presummed, int64_t n, const double *a, const do
         if (flat)
             hipLaunchKernelGGL((xs_fused<KIND, true>), dim3(4 * ng + ND), dim3(256), 0, s, n, a, b, c, w->ncells, w->ngroups,
                                (const double *)w->cellsum, gsum, prefix, w->cells, w->groups, w->batches, w->ready, mode, hist, iter, tol, done,
-                               out, w->xfer, g_xs_trace, (double *)nullptr, (const double *)nullptr);
+                               out, w->xfer, g_xs_trace, (double *)nullptr, (const double *)nullptr, g_xs_wgtrace, w->head);
         else
-            hipLaunchKernelGGL((xs_fused<KIND, false>), dim3(xu ? 5 * ((ng + 3) / 4) + ND : ng + ND), dim3(256), 0, s, n, a, b, c, w->ncells,
+            hipLaunchKernelGGL((xs_fused<KIND, false>), dim3(xu ? 5 * ((ng + 3 + 3) / 4) + ND : ng + 3 + ND), dim3(256), 0, s, n, a, b, c, w->ncells,
                                w->ngroups, (const double *)w->cellsum, gsum, prefix, w->cells, w->groups, w->batches, w->ready, mode, hist, iter,
-                               tol, done, out, w->xfer, g_xs_trace, xu ? xu_x : nullptr, xu ? xu_p : nullptr);
+                               tol, done, out, w->xfer, g_xs_trace, xu ? xu_x : nullptr, xu ? xu_p : nullptr, g_xs_wgtrace, w->head);
         CGH_HIP(hipGetLastError());
         return CGH_OK;
     }
@@ -1438,8 +1580,9 @@ cgh_xsum *cgh_xsum_create(int64_t n)
         w->xfer = nullptr;
     }
     const size_t nready = 2 * (size_t)((w->ngroups + 63) / 64 > 32 ? (w->ngroups + 63) / 64 : 32);  // (few cells: one batch per group, <= 32)
-    w->ready = (unsigned *)cgh_alloc(sizeof(unsigned) * nready);
-    if (w->ready && hipMemset(w->ready, 0, sizeof(unsigned) * nready) != hipSuccess) {
+    w->ready = (unsigned *)cgh_alloc(sizeof(unsigned) * (nready + 8));
+    w->head = w->ready ? w->ready + nready : nullptr;
+    if (w->ready && hipMemset(w->ready, 0, sizeof(unsigned) * (nready + 8)) != hipSuccess) {
         cgh_free(w->ready);
         w->ready = nullptr;
     }
@@ -1462,7 +1605,7 @@ size_t cgh_xsum_device_bytes(int64_t n)
     const size_t ncells = (size_t)((n + XS_CELL - 1) / XS_CELL), ngroups = (ncells + XS_GROUP - 1) / XS_GROUP;
     const size_t nready = 2 * ((ngroups + 63) / 64 > 32 ? (ngroups + 63) / 64 : 32);
     return xs_up256(sizeof(double) * 2 * ncells) + 2 * xs_up256(sizeof(double) * 2 * ngroups) + xs_up256(sizeof(xs_summary) * 2 * ncells) +
-           xs_up256(sizeof(xs_summary) * 2 * ngroups) + xs_up256(sizeof(double) * 4) + xs_up256(sizeof(unsigned) * nready) +
+           xs_up256(sizeof(xs_summary) * 2 * ngroups) + xs_up256(sizeof(double) * 4) + xs_up256(sizeof(unsigned) * (nready + 8)) +
            xs_up256(sizeof(xs_summary) * nready);
 }
 cgh_xsum *cgh_xsum_place(void *obj, size_t obj_bytes, int64_t n, void *dev, size_t dev_bytes, hipStream_t s)
@@ -1483,9 +1626,10 @@ cgh_xsum *cgh_xsum_place(void *obj, size_t obj_bytes, int64_t n, void *dev, size
     w->cells = (xs_summary *)take(sizeof(xs_summary) * 2 * (size_t)w->ncells);
     w->groups = (xs_summary *)take(sizeof(xs_summary) * 2 * (size_t)w->ngroups);
     w->xfer = (double *)take(sizeof(double) * 4);
-    w->ready = (unsigned *)take(sizeof(unsigned) * nready);
+    w->ready = (unsigned *)take(sizeof(unsigned) * (nready + 8));
+    w->head = w->ready + nready;
     w->batches = (xs_summary *)take(sizeof(xs_summary) * nready);
-    if (hipMemsetAsync(w->xfer, 0, sizeof(double) * 4, s) != hipSuccess || hipMemsetAsync(w->ready, 0, sizeof(unsigned) * nready, s) != hipSuccess)
+    if (hipMemsetAsync(w->xfer, 0, sizeof(double) * 4, s) != hipSuccess || hipMemsetAsync(w->ready, 0, sizeof(unsigned) * (nready + 8), s) != hipSuccess)
         return nullptr;
     return w;
 }
@@ -1506,9 +1650,17 @@ void cgh_xsum_free(cgh_xsum *w)
 
 // Profile of the serial walks that follow (see XS_PROF_ADD): 16 zeroed 64-bit words of device memory, or NULL to stop.
 extern "C" void cgh_xsum_set_trace(void *dev_224_words) { g_xs_trace = (long long *)dev_224_words; }
+extern "C" void cgh_xsum_set_wgtrace(void *dev_4_words_per_workgroup) { g_xs_wgtrace = (long long *)dev_4_words_per_workgroup; }
 extern "C" void cgh_xsum_set_prof(void *dev_16_words) { g_xs_prof = (long long *)dev_16_words; }
 
 double *cgh_xsum_cellsums(cgh_xsum *w) { return w ? w->cellsum : nullptr; }
+// where the producer of the next vector to be summed (both slots) may leave the sums of the 64-cell groups as well; a
+// producer that did says so with cgh_xsum_groups_written right before the sums' launch
+double *cgh_xsum_groupsums(cgh_xsum *w) { return w ? w->groupsum : nullptr; }
+void    cgh_xsum_groups_written(cgh_xsum *w)
+{
+    if (w) w->groups_presummed = true;
+}
 int64_t cgh_xsum_cells(const cgh_xsum *w) { return w ? w->ncells : 0; }
 
 // One rank's part of the sums of a vector spread over several ranks (rank order = element order): starts from the exact

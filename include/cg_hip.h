@@ -274,6 +274,9 @@ int  cgh_p2p_error(void);                          /* 1 after a timed-out wait (
 int  cgh_p2p_allreduce_f64(double *h_vals, int count);   /* 1 or 2 host doubles, summed in rank order */
 /* launcher helper: all-reduce up to 64 host doubles over the ranks (op 0 sum, 1 max, 2 min); one value = a barrier */
 int cgh_comm_allreduce_f64(double *h_vals, int count, int op);
+/* launcher diagnostic (collective): `reps` all-reduces of two doubles back to back through the peer-to-peer mailboxes (1) or
+ * ncclAllReduce (0), microseconds per exchange (HIP events around the loop) */
+int cgh_comm_bench_allreduce(int reps, int use_p2p, double *us_per_exchange);
 
 /* Device side of a rank: from a host partition, or generated on the device for the z-slab partition of the
  * seeded Poisson stencils (rank g owns planes [nz*g/G, nz*(g+1)/G)); d_b (may be NULL) gets the local rhs. */

@@ -42,3 +42,15 @@ def test_launcher_contract_with_ranks_sharing_the_gpu(N):
     first, last = d["config"]["residual_l1_half_first_last"]
     assert 0 < last < first                                   # the partitioned iteration converges
     assert abs(d["value"] - 30 / (d["ms_per_step"] * 30e-3)) < 1e-6 * d["value"]
+
+    # contract-complete for a driver-run multi-GPU record: the reference's CPU path beside it (rank 0), and one
+    # self-diagnosis line per rank on stderr (transport chosen and why, all-reduce latency alone, halo cost inside the SpMV)
+    cb = d["cpu_baseline"]
+    assert cb["value"] > 0 and cb["cores"] == 1 and cb["kind"] in ("reference", "port") and "compiled with" in cb["sample"]
+    diags = [json.loads(ln.split("[cg_hip bench_dist] ", 1)[1]) for ln in p.stderr.splitlines() if ln.startswith("[cg_hip bench_dist] ")]
+    assert sorted(g["rank"] for g in diags) == list(range(N))
+    for g in diags:
+        assert "diagnostics_failed" not in g, g
+        assert g["scalar_allreduce"].startswith("p2p") and g["halo_exchange"] == "p2p" and g["p2p_error_word"] == 0
+        assert g["allreduce_alone_us_per_exchange"]["p2p_mailbox_us"] > 0
+        assert g["own_spmv_ms"] > 0 and g["same_slab_without_neighbours_spmv_ms"] > 0
