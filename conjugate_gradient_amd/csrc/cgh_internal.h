@@ -205,6 +205,14 @@ int cgh_xsum_launch(cgh_xsum *w, int64_t n, const double *a, const double *b, co
 int cgh_xsum_launch_part(cgh_xsum *w, int64_t n, const double *a, const double *b, const double *c, const double *s_in,
                          double *s_out, const int *done, hipStream_t s, bool presummed);
 int cgh_xsum_finalize(const double *sums, int mode, double *hist, int iter, double tol, int *done, hipStream_t s);
+// ... or composed: every rank summarises its part at once, the ranks exchange at most 32 batch summaries each and every
+// rank walks them all (xsum.hip, xc_walk).  Collective over the ranks of L (mailboxes connected); idx numbers the sums of a
+// solve (the same on every rank); offsets: 2 doubles of device scratch.  CGH_EINVAL: the part is too long for one message.
+struct cgh_link;
+int cgh_xsum_composed_batches(const cgh_xsum *w);
+int cgh_xsum_launch_composed(cgh_xsum *w, const cgh_link *L, int64_t n, const double *a, const double *b, const double *c, int mode,
+                             double *hist, int iter, double tol, int *done, bool check_done, unsigned epoch, unsigned idx, double *offsets,
+                             hipStream_t s, bool presummed);
 double *cgh_xsum_cellsums(cgh_xsum *w);
 double *cgh_xsum_groupsums(cgh_xsum *w);       // [2][groups of 64 cells]: a producer may leave them too ...
 void    cgh_xsum_groups_written(cgh_xsum *w);   // ... and says so before the launch that consumes them

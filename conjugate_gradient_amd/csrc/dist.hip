@@ -243,6 +243,7 @@ struct cgh_dist {
     // GLOBAL vector -- order-exact sums (xsum.hip) chained through the ranks in rank order
     bool      strict = false;
     cgh_xsum *xs = nullptr;                        // this rank's part of the sums
+    bool      composed = false;                    // the sums are composed from the ranks' summaries (xsum.hip, xc_walk) instead of chained rank by rank
     double   *chain = nullptr;                     // [0..1] running exact sums as they travel, [2..3] this rank's contribution, [4..5] zeros
 };
 
@@ -648,6 +649,15 @@ static int strict_chain(cgh_dist *d, const double *a, const double *b, const dou
     double *run = d->chain, *mine = d->chain + 2, *zeros = d->chain + 4;
     const int  N = d->nranks;
     const bool frozen_check = mode != 3;
+    if (d->composed) {
+        // every rank summarises its part at once, the ranks exchange their (at most 32) batch summaries and every rank
+        // walks them all: one round instead of N (xsum.hip, "sums over several ranks, composed")
+        cgh_link L;
+        const int rc = cgh_p2p_link(&L);
+        if (rc) return rc;
+        return cgh_xsum_launch_composed(d->xs, &L, d->n_loc, a, b, c, mode, d->hist, iter, d->tol, d->done, frozen_check, d->epoch,
+                                        (unsigned)iter * 2u + (unsigned)sum, d->chain + 6, s, presummed);
+    }
     CGH_HIP(hipMemsetAsync(run, 0, sizeof(double) * 2, s));
     for (int q = 0; q < N; ++q) {
         if (q == d->rank) {
@@ -1067,6 +1077,21 @@ int cgh_dist_start(cgh_dist *d, const double *d_b, double *d_x, double tol, int 
         d->chain = (double *)cgh_alloc(sizeof(double) * 8);
         if (!d->xs || !d->chain) return CGH_ENOMEM;
         CGH_HIP(hipMemsetAsync(d->chain, 0, sizeof(double) * 8, s));
+        // Composed sums need the mailboxes and every rank's part within 32 batches of 64 groups (16.7M rows): the ranks
+        // agree (a host-level exchange, once per solve).  CGH_DIST_STRICT_COMPOSED=0 keeps the rank-by-rank chain of round 2.
+        d->composed = false;
+        if (g_rccl.p2p && !(getenv("CGH_DIST_STRICT_COMPOSED") && atoi(getenv("CGH_DIST_STRICT_COMPOSED")) == 0)) {
+            const int nb = cgh_xsum_composed_batches(d->xs);
+            double    ok[1] = {nb >= 1 && nb <= CGH_XC_MAX_BATCHES ? 1.0 : 0.0};
+            if (d->nranks > 1) {
+                CGH_HIP(hipStreamSynchronize(s));
+                rc = cgh_p2p_allreduce_f64(ok, 1);
+                if (rc) return rc;
+            } else {
+                ok[0] = ok[0] * 1.0;
+            }
+            d->composed = ok[0] == (double)d->nranks;
+        }
         return strict_chain(d, d->r, d->r, d->r, 3, 0, 1, false, s);  // (rounds N .. 2N-1: iteration 1 goes on at 2N)
     }
     if (g_rccl.p2p) {

@@ -21,6 +21,14 @@ constexpr int CGH_LINK_MAX_RANKS = 16, CGH_LINK_SLOTS = 4, CGH_LINK_WORDS = 4;
 // region 1 = exchanges numbered by iteration (this header), region 2 = rounds of the chained order-exact sums
 constexpr size_t CGH_LINK_REGION_WORDS = (size_t)CGH_LINK_SLOTS * CGH_LINK_MAX_RANKS * CGH_LINK_WORDS;
 constexpr long long CGH_LL_TIMEOUT_TICKS = 1000000000ll;  // 10 s of the 100 MHz constant clock
+// region 3 = the composed order-exact sums of the bit-identical multi-GPU mode (xsum.hip, xc_*): per slot and sender
+//   words [0, 4)                       the sender's approximate totals of the two sums (binade prediction of the ranks behind it)
+//   word  4                            the number of batches of 64 groups its part has
+//   words 8 + ((s 32 + b) 10 + w)      word w of the summary of batch b of sum s (five 64-bit words, low half first)
+//   words 648 + (s 32 + b) 2 + {0, 1}  the exact running sum behind batch b of sum s, when the sender had to walk that batch
+constexpr int    CGH_XC_MAX_BATCHES = 32, CGH_XC_WORDS = 800, CGH_XC_SUMMARY0 = 8, CGH_XC_RESULT0 = 648;
+constexpr size_t CGH_XC_REGION0 = 3 * CGH_LINK_REGION_WORDS;
+constexpr size_t CGH_XC_REGION_WORDS = (size_t)CGH_LINK_SLOTS * CGH_LINK_MAX_RANKS * CGH_XC_WORDS;
 
 struct cgh_link {
     uint64_t *const *peers;  // [nranks]: every rank's mailbox as mapped here
@@ -104,6 +112,34 @@ __device__ __forceinline__ double ll_wait(const uint64_t *lo_p, const uint64_t *
         }
     }
     return __longlong_as_double((long long)((hi << 32) | (lo & 0xffffffffull)));
+}
+
+// one 32-bit datum under its tag
+__device__ __forceinline__ void ll_store32(uint64_t *q, unsigned data, unsigned tag)
+{
+    __hip_atomic_store(q, ((uint64_t)tag << 32) | data, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ unsigned ll_wait32(const uint64_t *q, unsigned tag, int *err, bool *failed)
+{
+    uint64_t v = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if ((unsigned)(v >> 32) != tag) {
+        if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+            *failed = true;
+            return 0;
+        }
+        const long long t0 = wall_clock64();
+        while (true) {
+            __builtin_amdgcn_s_sleep(2);
+            v = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if ((unsigned)(v >> 32) == tag) break;
+            if (wall_clock64() - t0 > CGH_LL_TIMEOUT_TICKS) {
+                atomicExch(err, 1);
+                *failed = true;
+                return 0;
+            }
+        }
+    }
+    return (unsigned)v;
 }
 
 __device__ __forceinline__ double ll_read(const cgh_ll_halo &h, int64_t entry)

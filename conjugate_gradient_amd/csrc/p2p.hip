@@ -26,7 +26,7 @@ namespace {
 constexpr int P2P_MAX_RANKS = CGH_LINK_MAX_RANKS, P2P_SLOTS = CGH_LINK_SLOTS, P2P_WORDS = CGH_LINK_WORDS;
 // region 0: the exchanges of this file (numbered by g_p2p.seq); region 1: those folded into the kernels of the
 // iteration (halo_ll.h, numbered by solve and iteration)
-constexpr size_t P2P_BOX_WORDS = 3 * CGH_LINK_REGION_WORDS;  // host-numbered | per iteration | rounds of the strict chain
+constexpr size_t P2P_BOX_WORDS = 3 * CGH_LINK_REGION_WORDS + CGH_XC_REGION_WORDS;  // host-numbered | per iteration | rounds of the strict chain | composed sums
 
 struct p2p_state {
     bool      connected = false;

@@ -19,6 +19,7 @@
 #include "cgh_internal.h"
 #include "device_utils.h"
 #include "xsum.h"
+#include "halo_ll.h"
 
 struct cgh_xsum {
     int64_t     n = 0, ncells = 0, ngroups = 0;
@@ -1492,6 +1493,223 @@ __global__ void xs_finalize_kernel(const double *__restrict__ sums, int mode, do
     if (!frozen) xs_finalize(sums[0], sums[1], mode, hist, iter, tol, done, nullptr);
 }
 
+
+// ---------------------------------------------------------------------------------------------- sums over several ranks, composed
+// The bit-identical multi-GPU mode (dist.hip): the reference's left-to-right sum over a vector whose rows are spread over N
+// ranks, rank 0's first.  Round 2 chained the ranks (rank q summarised and walked its part only once rank q-1's exact sum
+// had arrived: N rounds per sum).  Here every rank summarises its part AT ONCE, against an approximate prefix of the
+// ranks before it (xc_offsets: the ranks' tree totals, exchanged through the mailboxes), joins its groups into at most 32
+// batch summaries (xc_reduce_batches) and hands those 40-byte maps to every other rank (xc_walk).  Every rank then walks
+// ALL ranks' batch summaries in rank order -- integer maps applied to the one exact running sum, a few instructions each
+// -- and holds the same total bits as every other rank at the end.  A batch whose summary does not apply to the sum that
+// really arrives (the head of the sum, a crossing and a tie in one batch, a misprediction) is walked by its OWNER, who
+// has the groups, cells and elements, and who sends the exact sum behind it to the others, which wait for it there.
+// Messages are tagged 64-bit words in mailbox region 3 (halo_ll.h); the slot comes from the count of exchanges executed.
+__device__ __forceinline__ uint64_t *xc_slot_of(uint64_t *box, unsigned seq, int sender)
+{
+    return box + CGH_XC_REGION0 + ((size_t)(seq & (CGH_LINK_SLOTS - 1)) * CGH_LINK_MAX_RANKS + (size_t)sender) * CGH_XC_WORDS;
+}
+
+// offsets[slot] = sum over the ranks before this one of their approximate totals (any order: a prediction)
+__global__ __launch_bounds__(256) void xc_offsets(cgh_link L, int64_t ngroups, const double *__restrict__ groupsum, int s0, int s1,
+                                                  double *__restrict__ offsets, const int *__restrict__ done, int check_done,
+                                                  unsigned epoch, unsigned idx)
+{
+    __shared__ double lds[4];
+    __shared__ double ex[2 * CGH_LINK_MAX_RANKS];
+    if (check_done && *done != 0) return;
+    const unsigned seq = (unsigned)*L.rounds;
+    const unsigned tag = cgh_ll_tag(epoch, idx);
+    double         mine[2] = {0.0, 0.0};
+    for (int slot = s0; slot <= s1; ++slot) mine[slot] = block_sum_partials(groupsum + slot * ngroups, (int)ngroups, 1, lds);
+    const int t = threadIdx.x;
+    if (t < 2 * L.nranks) {
+        const int peer = t >> 1, w = t & 1;
+        if (peer > L.me) {  // the ranks behind me want my totals
+            uint64_t *q = xc_slot_of(L.peers[peer], seq, L.me) + 2 * w;
+            ll_store(q, q + 1, mine[w], tag);
+        }
+        ex[t] = 0.0;
+        if (peer < L.me) {
+            const uint64_t *q = xc_slot_of(const_cast<uint64_t *>(L.box), seq, peer) + 2 * w;
+            ex[t] = ll_wait(q, q + 1, tag, L.err);
+        }
+    }
+    __syncthreads();
+    if (t < 2) {
+        double v = 0.0;
+        for (int r = 0; r < L.me; ++r) v += ex[2 * r + t];
+        offsets[t] = v;
+    }
+    if (t == 0) *L.rounds = (unsigned long long)seq + 1ull;
+}
+
+// batches[slot][bb] = join of the 64 items (groups; cells when there is no group level) of batch bb: one wave per (slot, batch)
+__global__ __launch_bounds__(256) void xc_reduce_batches(const xs_summary *__restrict__ items, int64_t nitems, int nb, int s0, int s1,
+                                                         xs_summary *__restrict__ batches, const int *__restrict__ done, int check_done)
+{
+    if (check_done && *done != 0) return;
+    const int lane = threadIdx.x & 63;
+    const int wv = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
+    const int slot = s0 + wv / nb, bb = wv % nb;
+    if (slot > s1) return;
+    const int64_t i = (int64_t)bb * 64 + lane;
+    xs_summary    q = xs_identity();
+    if (i < nitems) q = items[slot * nitems + i];
+    const xs_summary j = wave_join(q);
+    if (lane == 0) batches[slot * CGH_XC_MAX_BATCHES + bb] = j;
+}
+
+// s + (the elements of cell `cell` of this rank), left to right (one wave; `stage` = 128 doubles of LDS of its own)
+template <int KIND>
+__device__ __forceinline__ double xc_chain(double s, double *stage, int slot, int64_t n, const double *__restrict__ a,
+                                           const double *__restrict__ b, const double *__restrict__ c, int64_t cell)
+{
+    const int lane = threadIdx.x & 63;
+    double    t0, t1;
+    xs_cell_terms<KIND>(slot, n, a, b, c, cell, t0, t1);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();  // the previous cell's reads are over
+    *reinterpret_cast<double2 *>(stage + 2 * lane) = make_double2(t0, t1);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    return xs_chain(s, stage);
+}
+
+// the owner's walk of ONE of its batches from the exact running sum s: groups, then the cells of a group that fails, then
+// the elements of a cell that fails (as xd_sum, without its staging pools: only the batches the chain could not apply come here)
+template <int KIND>
+__device__ double xc_walk_own_batch(double s, double *stage, int slot, int64_t n, const double *__restrict__ a, const double *__restrict__ b,
+                                    const double *__restrict__ c, int64_t ncells, int64_t ngroups, const xs_summary *__restrict__ cells,
+                                    const xs_summary *__restrict__ groups, int bb)
+{
+    const int lane = threadIdx.x & 63;
+    cells += slot * ncells;
+    const xs_summary *items = groups ? groups + slot * ngroups : cells;
+    const int64_t     nitems = groups ? ngroups : ncells, i0 = (int64_t)bb * 64;
+    const int         cnt = (int)(nitems - i0 < 64 ? nitems - i0 : 64);
+    xs_summary        Gq = xs_identity();
+    if (lane < cnt) Gq = items[i0 + lane];
+    const int64_t Ginc = xs_scan(Gq, cnt);
+    int           gstart = 0;
+    while (gstart < cnt) {
+        const int f = xs_batch(Gq, Ginc, gstart, cnt, s);
+        if (f >= cnt) break;
+        const int64_t it = i0 + f;
+        if (!groups) {
+            s = xc_chain<KIND>(s, stage, slot, n, a, b, c, it);
+        } else {
+            const int64_t c0 = it * XS_GROUP;
+            const int     ccnt = (int)(ncells - c0 < XS_GROUP ? ncells - c0 : XS_GROUP);
+            xs_summary    Cq = xs_identity();
+            if (lane < ccnt) Cq = cells[c0 + lane];
+            const int64_t Cinc = xs_scan(Cq, ccnt);
+            int           cstart = 0;
+            while (cstart < ccnt) {
+                const int cf = xs_batch(Cq, Cinc, cstart, ccnt, s);
+                if (cf >= ccnt) break;
+                s = xc_chain<KIND>(s, stage, slot, n, a, b, c, c0 + cf);
+                cstart = cf + 1;
+            }
+        }
+        gstart = f + 1;
+    }
+    return s;
+}
+
+// One workgroup per rank: all four waves send this rank's batch summaries to every other rank; then wave w (w < number of
+// sums) walks sum S0 + w over the batch summaries of ALL ranks in rank order and finalises like seq_sums.
+template <int KIND>
+__global__ __launch_bounds__(256) void xc_walk(cgh_link L, int64_t n, const double *__restrict__ a, const double *__restrict__ b,
+                                               const double *__restrict__ c, int64_t ncells, int64_t ngroups,
+                                               const xs_summary *__restrict__ cells, const xs_summary *__restrict__ groups,
+                                               const xs_summary *__restrict__ batches, int nb, int mode, double *hist, int iter, double tol,
+                                               int *done, int check_done, unsigned epoch, unsigned idx)
+{
+    constexpr int S0 = KIND == XS_L1 ? 1 : 0, S1 = KIND == XS_DOT ? 0 : 1;
+    __shared__ __attribute__((aligned(16))) double stage[2][XS_CELL];
+    __shared__ double                              total[2];
+    if (check_done && *done != 0) return;
+    const unsigned seq = (unsigned)*L.rounds;
+    const unsigned tag = cgh_ll_tag(epoch, idx);
+    const int      lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();  // (everybody has read the count before thread 0 moves it on at the end)
+    // 1. my batch summaries (and their number) to every other rank
+    for (int peer = 0; peer < L.nranks; ++peer) {
+        if (peer == L.me) continue;
+        uint64_t *dst = xc_slot_of(L.peers[peer], seq, L.me);
+        if (threadIdx.x == 0) ll_store32(dst + 4, (unsigned)nb, tag);
+        for (int k = threadIdx.x; k < (S1 - S0 + 1) * nb * 10; k += 256) {
+            const int slot = S0 + k / (nb * 10), bb = (k / 10) % nb, w = k % 10;
+            const xs_summary &q = batches[slot * CGH_XC_MAX_BATCHES + bb];
+            const uint64_t    words[5] = {(uint64_t)q.A, (uint64_t)q.C, (uint64_t)q.Mlo, (uint64_t)q.Mhi,
+                                          (uint64_t)(uint32_t)q.E | ((uint64_t)(uint32_t)q.meta << 32)};
+            const uint64_t    v = words[w >> 1];
+            ll_store32(dst + CGH_XC_SUMMARY0 + (slot * CGH_XC_MAX_BATCHES + bb) * 10 + w, (unsigned)((w & 1) ? v >> 32 : v), tag);
+        }
+    }
+    // 2. the walk
+    if (wave <= S1 - S0) {
+        const int slot = S0 + wave;
+        double    s = 0.0;
+        bool      failed = false;
+        for (int q = 0; q < L.nranks && !failed; ++q) {
+            const uint64_t *src = xc_slot_of(const_cast<uint64_t *>(L.box), seq, q);
+            int             nbq = nb;
+            xs_summary      Bq = xs_identity();
+            if (q == L.me) {
+                if (lane < nb) Bq = batches[slot * CGH_XC_MAX_BATCHES + lane];
+            } else {
+                nbq = (int)ll_wait32(src + 4, tag, L.err, &failed);
+                nbq = nbq < 0 ? 0 : (nbq > CGH_XC_MAX_BATCHES ? CGH_XC_MAX_BATCHES : nbq);
+                if (lane < nbq) {
+                    uint64_t        words[5];
+                    const uint64_t *at = src + CGH_XC_SUMMARY0 + (slot * CGH_XC_MAX_BATCHES + lane) * 10;
+#pragma unroll
+                    for (int w = 0; w < 5; ++w) {
+                        const uint64_t lo = ll_wait32(at + 2 * w, tag, L.err, &failed), hi = ll_wait32(at + 2 * w + 1, tag, L.err, &failed);
+                        words[w] = (hi << 32) | lo;
+                    }
+                    Bq.A = (int64_t)words[0];
+                    Bq.C = (int64_t)words[1];
+                    Bq.Mlo = (int64_t)words[2];
+                    Bq.Mhi = (int64_t)words[3];
+                    Bq.E = (int32_t)(uint32_t)words[4];
+                    Bq.meta = (int32_t)(uint32_t)(words[4] >> 32);
+                }
+            }
+            failed = __ballot(failed) != 0ull;
+            if (failed) break;
+            const int64_t Binc = xs_scan(Bq, nbq);
+            int           start = 0;
+            while (start < nbq) {
+                const int fb = xs_batch(Bq, Binc, start, nbq, s);  // the longest prefix of batches that applies to s, applied
+                if (fb >= nbq) break;
+                // batch fb of rank q does not apply to the sum that arrives: its owner walks it and tells the others
+                if (q == L.me) {
+                    s = xc_walk_own_batch<KIND>(s, stage[wave], slot, n, a, b, c, ncells, ngroups, cells, groups, fb);
+                    if (lane < L.nranks && lane != L.me) {
+                        uint64_t *dst = xc_slot_of(L.peers[lane], seq, L.me) + CGH_XC_RESULT0 + (slot * CGH_XC_MAX_BATCHES + fb) * 2;
+                        ll_store(dst, dst + 1, s, tag);
+                    }
+                } else {
+                    const uint64_t *at = src + CGH_XC_RESULT0 + (slot * CGH_XC_MAX_BATCHES + fb) * 2;
+                    s = ll_wait(at, at + 1, tag, L.err);
+                    if (__hip_atomic_load(L.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) failed = true;
+                }
+                start = fb + 1;
+            }
+        }
+        if (lane == 0) total[slot] = failed ? __builtin_nan("") : s;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        xs_finalize(KIND == XS_L1 ? 0.0 : total[0], KIND == XS_DOT ? 0.0 : total[1], mode, hist, iter, tol, done, nullptr);
+        *L.rounds = (unsigned long long)seq + 1ull;
+    }
+}
+
 long long *g_xs_wgtrace = nullptr;  // device buffer of 4 words per workgroup of a fused launch, or NULL (cgh_xsum_set_wgtrace)
 long long *g_xs_prof = nullptr;  // device buffer of 16 words, or NULL (cgh_xsum_set_prof)
 long long *g_xs_trace = nullptr; // device buffer of 224 words, or NULL (cgh_xsum_set_trace): time stamps of the fused driver
@@ -1674,6 +1892,65 @@ int cgh_xsum_launch_part(cgh_xsum *w, int64_t n, const double *a, const double *
     if (a && b && !c) return launch_all<XS_DOT>(w, presummed, n, a, b, c, 1, nullptr, 0, 0.0, dn, nullptr, s, s_in, s_out);
     if (!a && !b && c) return launch_all<XS_L1>(w, presummed, n, a, b, c, 1, nullptr, 0, 0.0, dn, nullptr, s, s_in, s_out);
     if (a && a == b && a == c) return launch_all<XS_BOTH_SAME>(w, presummed, n, a, b, c, 1, nullptr, 0, 0.0, dn, nullptr, s, s_in, s_out);
+    return CGH_EINVAL;
+}
+
+
+// One of the reference's sums over a vector spread over the ranks of L, composed (see xc_walk): collective, every rank
+// launches the same sequence.  n / a / b / c / presummed as cgh_xsum_launch; offsets = 2 doubles of device scratch.
+// Returns CGH_EINVAL if this rank's part has more batches than a message holds (the caller then chains the ranks).
+int cgh_xsum_composed_batches(const cgh_xsum *w)
+{
+    if (!w) return 0;
+    const int64_t items = w->ncells <= XD_ITEMS ? w->ncells : w->ngroups;
+    return (int)((items + 63) / 64);
+}
+
+template <int KIND>
+static int launch_composed(cgh_xsum *w, const cgh_link &L, bool presummed, int64_t n, const double *a, const double *b, const double *c,
+                           int mode, double *hist, int iter, double tol, int *done, bool check_done, unsigned epoch, unsigned idx,
+                           double *offsets, hipStream_t s)
+{
+    constexpr int S0 = KIND == XS_L1 ? 1 : 0, S1 = KIND == XS_DOT ? 0 : 1;
+    const int      nb = cgh_xsum_composed_batches(w), cd = check_done ? 1 : 0;
+    const unsigned ng = (unsigned)w->ngroups;
+    if (nb < 1 || nb > CGH_XC_MAX_BATCHES) return CGH_EINVAL;
+    // approximate sums of every cell and group (the SpMV / the r update may have left the cells')
+    if (presummed) {
+        const int64_t waves = (int64_t)(S1 - S0 + 1) * w->ngroups;
+        hipLaunchKernelGGL(xs_group_sums, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, w->ncells, w->ngroups, (const double *)w->cellsum,
+                           w->groupsum, S0, S1);
+    } else {
+        hipLaunchKernelGGL((xs_cell_sums<KIND>), dim3(ng), dim3(256), 0, s, n, a, b, c, w->ncells, w->ngroups, w->cellsum, w->groupsum);
+    }
+    w->groups_presummed = false;
+    hipLaunchKernelGGL(xc_offsets, dim3(1), dim3(256), 0, s, L, w->ngroups, (const double *)w->groupsum, S0, S1, offsets, (const int *)done, cd,
+                       epoch, 2u * idx);
+    const bool  flat = w->ncells <= XD_ITEMS;
+    xs_summary *grp = flat ? nullptr : w->groups;
+    if (flat)
+        hipLaunchKernelGGL((xs_summarize<KIND, true>), dim3(4 * ng), dim3(256), 0, s, n, a, b, c, w->ncells, w->ngroups,
+                           (const double *)w->cellsum, (const double *)w->groupsum, (const double *)nullptr, w->cells, grp, (const double *)offsets);
+    else
+        hipLaunchKernelGGL((xs_summarize<KIND, false>), dim3(ng), dim3(256), 0, s, n, a, b, c, w->ncells, w->ngroups,
+                           (const double *)w->cellsum, (const double *)w->groupsum, (const double *)nullptr, w->cells, grp, (const double *)offsets);
+    hipLaunchKernelGGL(xc_reduce_batches, dim3((unsigned)(((S1 - S0 + 1) * nb + 3) / 4)), dim3(256), 0, s,
+                       (const xs_summary *)(flat ? w->cells : w->groups), flat ? w->ncells : w->ngroups, nb, S0, S1, w->batches, (const int *)done, cd);
+    hipLaunchKernelGGL((xc_walk<KIND>), dim3(1), dim3(256), 0, s, L, n, a, b, c, w->ncells, w->ngroups, (const xs_summary *)w->cells,
+                       (const xs_summary *)grp, (const xs_summary *)w->batches, nb, mode, hist, iter, tol, done, cd, epoch, 2u * idx + 1u);
+    CGH_HIP(hipGetLastError());
+    return CGH_OK;
+}
+
+int cgh_xsum_launch_composed(cgh_xsum *w, const cgh_link *L, int64_t n, const double *a, const double *b, const double *c, int mode,
+                             double *hist, int iter, double tol, int *done, bool check_done, unsigned epoch, unsigned idx, double *offsets,
+                             hipStream_t s, bool presummed)
+{
+    if (!w || !L || n != w->n || !offsets) return CGH_EINVAL;
+    if (a && b && !c) return launch_composed<XS_DOT>(w, *L, presummed, n, a, b, c, mode, hist, iter, tol, done, check_done, epoch, idx, offsets, s);
+    if (!a && !b && c) return launch_composed<XS_L1>(w, *L, presummed, n, a, b, c, mode, hist, iter, tol, done, check_done, epoch, idx, offsets, s);
+    if (a && a == b && a == c)
+        return launch_composed<XS_BOTH_SAME>(w, *L, presummed, n, a, b, c, mode, hist, iter, tol, done, check_done, epoch, idx, offsets, s);
     return CGH_EINVAL;
 }
 

@@ -220,14 +220,16 @@ def test_multi_process_loop_from_partition(tmp_path, tag, G, env):
     _check_against_golden(hists[0].shape[0], hists[0], xs, g)
 
 
-@pytest.mark.parametrize("tag,G", [("cylinder_2000", 2), ("cylinder_8000", 4), ("cylinder_32k", 2), ("poisson7_16", 2),
-                                   ("poisson27_12x10x8", 4), ("poisson7_32x24x20", 8), ("cylinder_2000", 8),
-                                   ("poisson7_32x24x20", 3), ("cylinder_32k", 8)])
-def test_multi_process_strict_mode_is_bit_identical(tmp_path, tag, G):
+@pytest.mark.parametrize("tag,G,composed", [("cylinder_2000", 2, 1), ("cylinder_8000", 4, 1), ("cylinder_32k", 2, 1), ("poisson7_16", 2, 1),
+                                            ("poisson27_12x10x8", 4, 1), ("poisson7_32x24x20", 8, 1), ("cylinder_2000", 8, 1),
+                                            ("poisson7_32x24x20", 3, 1), ("cylinder_32k", 8, 1),
+                                            ("cylinder_8000", 3, 0), ("poisson7_32x24x20", 4, 0)])
+def test_multi_process_strict_mode_is_bit_identical(tmp_path, tag, G, composed):
     """cgh_dist_set_strict: with 2, 3, 4 and 8 PROCESSES the whole trajectory (residual, r.r, alpha, beta of every
     iteration), the converging iteration and the gathered x equal the reference's goldens of the UNdistributed system bit
     for bit -- the OpenFOAM systems included, where the throughput-mode loop only agrees to rounding.  The order-exact
-    sums are chained through the ranks in rank order (dist.hip, strict_chain)."""
+    sums are COMPOSED from the ranks' batch summaries (every rank summarises its part at once, every rank walks all of
+    them: xsum.hip, xc_walk); composed = 0 (CGH_DIST_STRICT_COMPOSED=0): chained rank by rank as in round 2."""
     import os
     import subprocess
     import sys
@@ -235,7 +237,8 @@ def test_multi_process_strict_mode_is_bit_identical(tmp_path, tag, G):
     mi, tol = int(g["max_iter"]), float(g["tol"])
     worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "dist_worker.py")
     procs = [subprocess.Popen([sys.executable, worker, str(r), str(G), str(tmp_path), "tag", tag, "0", "0", str(mi), str(tol), "strict"],
-                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(G)]
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
+                              env=dict(os.environ, CGH_DIST_STRICT_COMPOSED=str(composed))) for r in range(G)]
     outs = []
     for p in procs:
         try:

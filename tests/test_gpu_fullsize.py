@@ -61,15 +61,23 @@ def _rel(a, b):
 def test_config3_256cubed_as_8_ranks_vs_one_gpu_strict(tmp_path, cga):
     """256^3 7-point over 8 processes, 100 iterations of the throughput loop: every rank's history bit-identical to every
     other's; residual and r.r within 1e-10 of the one-GPU STRICT trajectory (the reference's order); x within 1e-9."""
-    G, N, iters = 8, 256, 100
-    procs = _ranks(tmp_path, G, (N, N, N), 7, iters, 0, 1, 280)
+    G, N, iters, strict_iters = 8, 256, 100, 30
+    procs = _ranks(tmp_path, G, (N, N, N), 7, iters, strict_iters, 1, 280)
     n = N ** 3
     b = cga.DeviceVector(n); x = cga.DeviceVector(n)
     A = cga.Matrix.poisson(N, N, N, 7, 0x5EED0001, cga.LAYOUT_ELL, b)
     rep, want = cga.cg_solve(A, b, x, fixed_iters=iters, strict=1)
     xr = x.to_host()
+    rep, want_s = cga.cg_solve(A, b, x, fixed_iters=strict_iters, strict=1)
+    xs1 = x.to_host()
     A.free()
     outs = _join(procs)
+    # the bit-identical mode over the 8 ranks (order-exact sums composed from the ranks' batch summaries): history and x
+    # equal the one-GPU strict solve bit for bit
+    for r in range(G):
+        assert same_bits_nan(np.load(os.path.join(tmp_path, "hist_strict_%d.npy" % r)), want_s)
+    assert np.array_equal(bits(np.concatenate([np.load(os.path.join(tmp_path, "x_strict_%d.npy" % r)) for r in range(G)])), bits(xs1))
+    print("\n[config 3, 8 ranks on one GPU, bit-identical mode] " + " | ".join(l for l in outs[0].strip().splitlines() if "strict:" in l))
     hists = [np.load(os.path.join(tmp_path, "hist_fast_%d.npy" % r)) for r in range(G)]
     for h in hists[1:]:
         assert same_bits_nan(h, hists[0])
