@@ -27,6 +27,7 @@
 #include "device_utils.h"
 
 #include "cg_kernels.h"
+#include "cg_persistent.h"
 
 namespace {
 
@@ -97,6 +98,9 @@ struct cgh_solver {
     int              *done = nullptr;
     cgh_xsum         *xs = nullptr;   // order-exact parallel sums (strict mode of long vectors), created on demand
     bool              no_alloc = false;  // cgh_cg_solve_noalloc: no launch of this solver may allocate
+    // one resident launch per batch of iterations (cg_persistent.h): tagged images of r (pl) and of the workgroups' partials
+    uint64_t         *pl = nullptr, *pa = nullptr, *pb = nullptr;
+    unsigned          epoch = 0;         // of the current solve: part of every tag
     std::vector<hipEvent_t> kev;      // SpMV kernel brackets (time_kernels)
     // HIP graphs of `count` iterations (launch-bound sizes): kernels take the iteration number from the device
     std::vector<std::pair<int, hipGraphExec_t>> graphs;
@@ -190,6 +194,9 @@ void cgh_solver_free(cgh_solver *sv)
     cgh_free(sv->hist);
     cgh_free(sv->done);
     cgh_xsum_free(sv->xs);
+    cgh_free(sv->pl);
+    cgh_free(sv->pa);
+    cgh_free(sv->pb);
     delete sv;
 }
 
@@ -228,6 +235,8 @@ int cgh_solver_start(cgh_solver *sv, const double *d_b, double *d_x, double tol,
     sv->strict = strict != 0;
     sv->queued = 0;
     sv->base = 0;
+    static unsigned solve_epoch = 0;
+    sv->epoch = ++solve_epoch;
     for (hipEvent_t e : sv->kev) (void)hipEventDestroy(e);
     sv->kev.clear();
     for (auto &g : sv->graphs) (void)hipGraphExecDestroy(g.second);  // the captured launches carry x, b, tol, strict
@@ -265,9 +274,75 @@ int cgh_solver_start(cgh_solver *sv, const double *d_b, double *d_x, double tol,
 
 } // extern "C"
 
+// Small systems in throughput mode: can this solver's iterations run as one resident launch (cg_persistent.h)?  At most
+// 256 tiles (all workgroups resident at once, one lane per partial), the vector path of the ELL SpMV with a compile-time
+// width, no preconditioner.  CGH_PERSISTENT=0 keeps the three launches per iteration.
+static bool persistent_eligible(const cgh_solver *sv)
+{
+    const cgh_matrix *m = sv->m;
+    if (!g_cfg.persistent || sv->strict || sv->no_alloc || sv->precond != CGH_PRECOND_NONE || g_cfg.serpentine) return false;
+    if (m->layout != CGH_LAYOUT_ELL || g_cfg.ell_generic || m->K < 1 || m->K > 8) return false;
+    if ((m->n + 2 * CGH_BLOCK - 1) / (2 * CGH_BLOCK) > CGP_MAX_TILES) return false;
+    if (!cgh_ell_vector_path(m, sv->p, sv->Ap) || (reinterpret_cast<uintptr_t>(sv->x) & 15u)) return false;
+    return m->dict_state == 2 || (m->dict_state == 1 && m->dict_mode == 1);
+}
+
+static long long *g_persistent_trace = nullptr;  // tools: cgh_persistent_set_trace
+
+template <int DICT>
+static void launch_persistent(cgh_solver *sv, int tiles, int first_iter, int count, hipStream_t s)
+{
+    const cgh_matrix *m = sv->m;
+    const void       *cols = DICT ? (const void *)m->cols8 : (const void *)m->cols;
+#define CGH_PERSISTENT_CASE(KK)                                                                                                 \
+    case KK:                                                                                                                    \
+        hipLaunchKernelGGL((cg_persistent<KK, DICT>), dim3(tiles), dim3(CGH_BLOCK), 0, s, m->n, (const double *)m->diag,        \
+                           (const double *)m->vals, cols, (const int *)m->off_tab, sv->x, sv->r, sv->p, sv->pl, sv->pa, sv->pb, \
+                           sv->hist, first_iter, count, sv->tol, sv->done, sv->epoch, g_persistent_trace);                      \
+        break;
+    switch (m->K) {
+        CGH_PERSISTENT_CASE(1)
+        CGH_PERSISTENT_CASE(2)
+        CGH_PERSISTENT_CASE(3)
+        CGH_PERSISTENT_CASE(4)
+        CGH_PERSISTENT_CASE(5)
+        CGH_PERSISTENT_CASE(6)
+        CGH_PERSISTENT_CASE(7)
+        CGH_PERSISTENT_CASE(8)
+    }
+#undef CGH_PERSISTENT_CASE
+}
+
+static int enqueue_persistent(cgh_solver *sv, int count)
+{
+    hipStream_t s = g_cgh.stream;
+    const int   tiles = (int)((sv->n + 2 * CGH_BLOCK - 1) / (2 * CGH_BLOCK));
+    if (!sv->pl) {
+        // images: two tagged words per entry of r (whole tiles: idle lanes of the last tile read their own slot), four per
+        // workgroup for p.Ap and for (r.r, |r|_1); a fresh buffer carries tag 0, which no exchange uses
+        const size_t pl_bytes = sizeof(uint64_t) * 2 * (size_t)tiles * 2 * CGH_BLOCK, part_bytes = sizeof(uint64_t) * 4 * CGP_MAX_TILES;
+        sv->pl = (uint64_t *)cgh_alloc(pl_bytes);
+        sv->pa = (uint64_t *)cgh_alloc(part_bytes);
+        sv->pb = (uint64_t *)cgh_alloc(part_bytes);
+        if (!sv->pl || !sv->pa || !sv->pb) return CGH_ENOMEM;
+        CGH_HIP(hipMemsetAsync(sv->pl, 0, pl_bytes, s));
+        CGH_HIP(hipMemsetAsync(sv->pa, 0, part_bytes, s));
+        CGH_HIP(hipMemsetAsync(sv->pb, 0, part_bytes, s));
+    }
+    const int first = sv->queued + 1;
+    if (sv->m->dict_state == 1)
+        launch_persistent<1>(sv, tiles, first, count, s);
+    else
+        launch_persistent<0>(sv, tiles, first, count, s);
+    sv->queued += count;
+    CGH_HIP(hipGetLastError());
+    return CGH_OK;
+}
+
 // Enqueue `count` iterations.  device_iter: the kernels read the iteration number from the device (graph capture).
 static int enqueue_iterations(cgh_solver *sv, int count, int time_kernels, bool device_iter)
 {
+    if (count > 0 && !time_kernels && !device_iter && persistent_eligible(sv)) return enqueue_persistent(sv, count);
     hipStream_t   s = g_cgh.stream;
     const int64_t n = sv->n;
     const int     vg = sv->vgrid;
@@ -398,16 +473,28 @@ int cgh_solver_iterate(cgh_solver *sv, int count, int time_kernels)
     return CGH_OK;
 }
 
+// Tools: per-workgroup time stamps of the resident launch (8 long long per workgroup, 256 workgroups; NULL switches off).
+int cgh_persistent_set_trace(long long *d_trace)
+{
+    g_persistent_trace = d_trace;
+    return CGH_OK;
+}
+
 // Drain the stream and read the device's verdict: *done_iter = converging iteration (0 = not yet).
 int cgh_solver_poll(cgh_solver *sv, int *done_iter, int *queued)
 {
     CGH_REQUIRE_READY(CGH_ENODEV);
     if (!sv) return CGH_EINVAL;
-    int d = 0;
-    CGH_HIP(hipMemcpyAsync(&d, sv->done, sizeof(int), hipMemcpyDeviceToHost, g_cgh.stream));
+    int d[4] = {0, 0, 0, 0};
+    CGH_HIP(hipMemcpyAsync(d, sv->done, sizeof(int) * 4, hipMemcpyDeviceToHost, g_cgh.stream));
     CGH_HIP(hipStreamSynchronize(g_cgh.stream));
-    if (done_iter) *done_iter = d;
+    if (done_iter) *done_iter = d[0];
     if (queued) *queued = sv->queued;
+    if (d[3] != 0) {
+        cgh_set_error("cgh_solver_poll: a workgroup of the resident CG launch waited 2 s for another one (is the GPU shared? "
+                      "CGH_PERSISTENT=0 keeps three launches per iteration); the results are NaN");
+        return CGH_EHIP;
+    }
     return CGH_OK;
 }
 
@@ -540,7 +627,8 @@ int cgh_cg_solve_sink(const cgh_matrix *m, const double *d_b, double *d_x, const
         }
         int64_t chunk = total - sv->base - sv->queued;
         if (chunk > window - sv->queued) chunk = window - sv->queued;
-        if (!fixed && chunk > check) chunk = check;
+        // (the resident launch of small systems leaves at the converging iteration by itself: no need to look that often)
+        if (!fixed && chunk > check && !(opts->time_kernels == 0 && persistent_eligible(sv))) chunk = check;
         rc = cgh_solver_iterate(sv, (int)chunk, opts->time_kernels);
         if (rc) return rc;
         if (!fixed) {

@@ -126,6 +126,7 @@ struct cgh_config {
     int    serpentine = 0;      // CGH_SERPENTINE: alternate the sweep direction of the iteration's kernels
     int    vec_variant = -1;    // CGH_VEC_VARIANT: cache-hint variant of the vector kernels, -1 = by working-set size
     int    graph = 0;           // CGH_GRAPH: replay batches of iterations from HIP graphs
+    int    persistent = 1;      // CGH_PERSISTENT: throughput-mode solves of <= 131072 rows run as one resident launch per batch
     int64_t graph_max_rows = 1 << 21; // CGH_GRAPH_MAX_ROWS
     int csrb_rpw = 1024;        // CGH_CSRB_RPW: rows per wave-block of the column-blocked CSR (512 | 1024 | 2048)
     int csrb_slab_bits = 17;    // CGH_CSRB_SLAB_BITS: log2 of the columns per slab (2^17 doubles = 1 MiB of x)
@@ -220,6 +221,7 @@ int64_t cgh_xsum_cells(const cgh_xsum *w);
 
 // p2p.hip -- scalar all-reduce over peer stores (multi-GPU path); W-interleaved partials in, W sums out
 int cgh_p2p_launch(int W, const double *partials, int count, double *out, hipStream_t s);
+bool cgh_ell_vector_path(const cgh_matrix *m, const double *x, const double *y);  // spmv_ell.hip: two rows per lane, 16-byte loads
 bool cgh_fits_llc(const cgh_matrix *m, double times);   // spmv_ell.hip: one iteration's working set fits `times` Infinity Caches
 struct cgh_link;
 struct cgh_ll_halo;

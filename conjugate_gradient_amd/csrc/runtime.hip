@@ -64,6 +64,7 @@ static void read_env_knobs()
     g_cfg.serpentine = env_int("CGH_SERPENTINE", g_cfg.serpentine);
     g_cfg.vec_variant = env_int("CGH_VEC_VARIANT", g_cfg.vec_variant);
     g_cfg.graph = env_int("CGH_GRAPH", g_cfg.graph);
+    g_cfg.persistent = env_int("CGH_PERSISTENT", g_cfg.persistent);
     if (getenv("CGH_GRAPH_MAX_ROWS")) g_cfg.graph_max_rows = atoll(getenv("CGH_GRAPH_MAX_ROWS"));
     g_cfg.csrb_rpw = env_int("CGH_CSRB_RPW", g_cfg.csrb_rpw);
     g_cfg.csrb_slab_bits = env_int("CGH_CSRB_SLAB_BITS", g_cfg.csrb_slab_bits);
@@ -164,6 +165,12 @@ int cgh_config_sell_sigma(int sigma_rows)
 {
     if (sigma_rows < 0) return CGH_EINVAL;
     if (sigma_rows) cgh_config_set(&g_cfg.sell_sigma, sigma_rows < 64 ? 64 : sigma_rows);
+    return CGH_OK;
+}
+
+int cgh_config_persistent(int on)
+{
+    cgh_config_set(&g_cfg.persistent, on ? 1 : 0);
     return CGH_OK;
 }
 

@@ -41,6 +41,7 @@ __device__ __forceinline__ T stream_load(const T *p)
 // Tuning variants (env CGH_ELL_VARIANT, default = the shipped one): bit0 = XCD-chunked tile walk,
 // bit1 = non-temporal matrix loads, bit2 = ablation (no gather; wrong results), bit3 = non-temporal y store.
 constexpr int VAR_DEFAULT = 11;
+constexpr int CGH_ELL_SMALL_TILES = 256;
 
 // Column ids of rows i0, i0+1 in slot s (-1 = pad).  DICT: one byte per entry, an index into the table of the
 // matrix's distinct (col - row) offsets (staged in LDS), 255 = pad -- 9 instead of 12 bytes per stored entry.
@@ -101,9 +102,13 @@ __global__ __launch_bounds__(CGH_BLOCK) void spmv_ell_r2(int64_t n, int Krt, con
     // t = 64*(q/8) + 8*(j%8) + q%8 with q = j/8, a bijection on every aligned group of 64 tiles.  A row's
     // +-1 / +-nx neighbours then almost always belong to the same XCD's chunk, so each x line is fetched
     // into one L2 instead of two or three (measured: SpMV FETCH_SIZE, profiles/).
+    // Up to CGH_ELL_SMALL_TILES tiles everything is resident at once and lives in the caches: tile t is simply workgroup t's
+    // (ell_grid_rows gives every tile its own workgroup), which is also the shape the resident CG launch of small systems
+    // reproduces bit for bit (cg_persistent.h).
     const int64_t tiles = (pairs + CGH_BLOCK - 1) / CGH_BLOCK;
     const int64_t tiles64 = (tiles + 63) & ~(int64_t)63;
-    constexpr bool REMAP = (VAR & 1) != 0, NT = (VAR & 2) != 0, NOGATHER = (VAR & 4) != 0, NTSTORE = (VAR & 8) != 0;
+    constexpr bool NT = (VAR & 2) != 0, NOGATHER = (VAR & 4) != 0, NTSTORE = (VAR & 8) != 0;
+    const bool     REMAP = (VAR & 1) != 0 && tiles > CGH_ELL_SMALL_TILES;
     for (int64_t jj = blockIdx.x; jj < tiles64; jj += gridDim.x) {
         const int64_t j = rev ? tiles64 - 1 - jj : jj;
         const int64_t q = j >> 3;
@@ -449,6 +454,8 @@ static inline bool ell_vector_path(const cgh_matrix *m, const double *x, const d
            (reinterpret_cast<uintptr_t>(m->cols) & 7u) == 0;
 }
 
+bool cgh_ell_vector_path(const cgh_matrix *m, const double *x, const double *y) { return ell_vector_path(m, x, y); }
+
 // Does one CG iteration's working set on this matrix (matrix + the four vectors) fit the Infinity Cache with room to
 // spare (`times` = 1), or `times` of them?  CGH_LLC_MB sets the limit (default 224; 0 = never).  Measured (us/iteration,
 // 7-point, hints on -> off): 1M rows 38.9 -> 34.2, 2.1M 59.9 -> 53.7; at 4.2M (394 MB) only the vector kernels gain
@@ -464,6 +471,7 @@ static int ell_grid_rows(int64_t rows)
 {
     // tiles of 512 rows (256 threads x 2 rows); grid a multiple of 8 so tile%8 -> XCD group is stable
     const int64_t tiles = (rows + 2 * CGH_BLOCK - 1) / (2 * CGH_BLOCK);
+    if (tiles <= CGH_ELL_SMALL_TILES) return (int)(tiles < 1 ? 1 : tiles);  // small: one workgroup per tile, in order
     int           g = cgh_stream_grid(tiles, 8);
     if (g >= 8) g -= g % 8;
     return g;

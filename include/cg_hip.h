@@ -114,6 +114,15 @@ int     cgh_config_sell_sigma(int sigma_rows);
  * products in the order of the stream (the same bits on every run, about 14 % slower), 0 = as the LDS atomics retire (the
  * default), < 0 keeps. */
 int     cgh_config_pb(int span_bits, int64_t target_entries, int split, int ordered);
+/* Throughput-mode (strict = 0) solves of ELL matrices of at most 131 072 rows and at most 8 slots run their iterations as
+ * ONE resident launch per batch (csrc/cg_persistent.h: workgroups keep their rows in registers and exchange p and the
+ * partial sums as tagged words; same bits as the three launches per iteration).  0 switches that off (also CGH_PERSISTENT=0),
+ * 1 on (the default).  The launch needs its <= 256 workgroups resident together: on a GPU shared with other work a wait
+ * gives up after 2 s and cgh_solver_poll reports it. */
+int     cgh_config_persistent(int on);
+/* Tools (tools/quick_persistent.py): the resident launch leaves, per workgroup, the ticks (100 MHz) its first lane spent in
+ * five sections of the iteration, summed over the launch, in d_trace[8 w + k] (device memory, 256 x 8 values); NULL = off. */
+int     cgh_persistent_set_trace(long long *d_trace);
 /* Host-side partition of the two-phase layout (no GPU needed; exported for tests): cuts G groups of 256 rows (cum[g] =
  * entries before group g, cum[G] = all) into consecutive blocks of at most max_groups groups and, where that leaves a
  * choice, at most `target` entries.  bnd_g[0..B] receives the boundaries in groups.  Returns B. */
