@@ -473,6 +473,9 @@ int cgh_solver_iterate(cgh_solver *sv, int count, int time_kernels)
     return CGH_OK;
 }
 
+// 1 if this solver's next iterations run as one resident launch per batch (cg_persistent.h): after cgh_solver_start.
+int cgh_solver_is_resident(const cgh_solver *sv) { return sv && persistent_eligible(sv) ? 1 : 0; }
+
 // Tools: per-workgroup time stamps of the resident launch (8 long long per workgroup, 256 workgroups; NULL switches off).
 int cgh_persistent_set_trace(long long *d_trace)
 {

@@ -231,9 +231,11 @@ __global__ __launch_bounds__(CGH_BLOCK) void cg_persistent(int64_t n, const doub
         double a1 = add_rn(0.0, mul_rn(dg.y, pv.y));
 #pragma unroll
         for (int s = 0; s < KT; ++s) {
+            // (every lane reads LDS, at a wrapped index where its column is outside the tile: no branches)
             const int    l0 = c[s].x - tile0, l1 = c[s].y - tile0;
-            const double g0 = (unsigned)l0 < 2u * CGH_BLOCK ? ptile[l0] : gp0[s];
-            const double g1 = (unsigned)l1 < 2u * CGH_BLOCK ? ptile[l1] : gp1[s];
+            const double q0 = ptile[l0 & (2 * CGH_BLOCK - 1)], q1 = ptile[l1 & (2 * CGH_BLOCK - 1)];
+            const double g0 = (unsigned)l0 < 2u * CGH_BLOCK ? q0 : gp0[s];
+            const double g1 = (unsigned)l1 < 2u * CGH_BLOCK ? q1 : gp1[s];
             const double t0 = madd_rn(a0, v[s].x, g0);
             const double t1 = madd_rn(a1, v[s].y, g1);
             a0 = c[s].x >= 0 ? t0 : a0;

@@ -120,6 +120,8 @@ int     cgh_config_pb(int span_bits, int64_t target_entries, int split, int orde
  * 1 on (the default).  The launch needs its <= 256 workgroups resident together: on a GPU shared with other work a wait
  * gives up after 2 s and cgh_solver_poll reports it. */
 int     cgh_config_persistent(int on);
+struct cgh_solver;
+int     cgh_solver_is_resident(const struct cgh_solver *sv);  /* after cgh_solver_start: 1 if its iterations take that path */
 /* Tools (tools/quick_persistent.py): the resident launch leaves, per workgroup, the ticks (100 MHz) its first lane spent in
  * five sections of the iteration, summed over the launch, in d_trace[8 w + k] (device memory, 256 x 8 values); NULL = off. */
 int     cgh_persistent_set_trace(long long *d_trace);
