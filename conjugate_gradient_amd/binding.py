@@ -67,6 +67,7 @@ def lib():
     L.cgh_config_persistent.argtypes = [C.c_int]
     L.cgh_persistent_set_trace.argtypes = [C.c_void_p]
     L.cgh_solver_is_resident.argtypes = [C.c_void_p]
+    L.cgh_persistent_launches.restype = C.c_longlong
     L.cgh_csrb_plan_host.argtypes = [i64, ip, C.c_int, ip, ip]
     L.cgh_csrb_plan_host.restype = i64
     L.cgh_config_pb.argtypes = [C.c_int, i64, C.c_int, C.c_int]

@@ -101,6 +101,8 @@ struct cgh_solver {
     // one resident launch per batch of iterations (cg_persistent.h): tagged images of r (pl) and of the workgroups' partials
     uint64_t         *pl = nullptr, *pa = nullptr, *pb = nullptr;
     unsigned          epoch = 0;         // of the current solve: part of every tag
+    unsigned          tag_period = ~0u;  // epoch >> CGP_EPOCH_BITS when the images were last cleared (tags repeat beyond that)
+    unsigned         *tag_period_home = nullptr;  // where that lives when the images outlive the solver (the no-allocation workspace)
     std::vector<hipEvent_t> kev;      // SpMV kernel brackets (time_kernels)
     // HIP graphs of `count` iterations (launch-bound sizes): kernels take the iteration number from the device
     std::vector<std::pair<int, hipGraphExec_t>> graphs;
@@ -280,14 +282,21 @@ int cgh_solver_start(cgh_solver *sv, const double *d_b, double *d_x, double tol,
 static bool persistent_eligible(const cgh_solver *sv)
 {
     const cgh_matrix *m = sv->m;
-    if (!g_cfg.persistent || sv->strict || sv->no_alloc || sv->precond != CGH_PRECOND_NONE || g_cfg.serpentine) return false;
+    if (!g_cfg.persistent || sv->strict || sv->precond != CGH_PRECOND_NONE || g_cfg.serpentine) return false;
+    if (sv->no_alloc && !sv->pl) return false;  // a solver that must not allocate brings the images along or does without
     if (m->layout != CGH_LAYOUT_ELL || g_cfg.ell_generic || m->K < 1 || m->K > 8) return false;
     if ((m->n + 2 * CGH_BLOCK - 1) / (2 * CGH_BLOCK) > CGP_MAX_TILES) return false;
     if (!cgh_ell_vector_path(m, sv->p, sv->Ap) || (reinterpret_cast<uintptr_t>(sv->x) & 15u)) return false;
-    return m->dict_state == 2 || (m->dict_state == 1 && m->dict_mode == 1);
+    // (dict_state 0: a solver that must not allocate has not built the column dictionary either -- int32 columns, as its SpMV)
+    if (!(m->dict_state == 2 || (m->dict_state == 1 && m->dict_mode == 1) || (m->dict_state == 0 && sv->no_alloc))) return false;
+    // A captured launch would be replayed with the SAME tags over the previous replay's images: not under capture
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(g_cgh.stream, &cap);
+    return cap == hipStreamCaptureStatusNone;
 }
 
 static long long *g_persistent_trace = nullptr;  // tools: cgh_persistent_set_trace
+static long long  g_persistent_launches = 0;     // tests: cgh_persistent_launches
 
 template <int DICT>
 static void launch_persistent(cgh_solver *sv, int tiles, int first_iter, int count, hipStream_t s)
@@ -317,24 +326,30 @@ static int enqueue_persistent(cgh_solver *sv, int count)
 {
     hipStream_t s = g_cgh.stream;
     const int   tiles = (int)((sv->n + 2 * CGH_BLOCK - 1) / (2 * CGH_BLOCK));
+    // images: two tagged words per entry of r (whole tiles), four per workgroup for p.Ap and for (r.r, |r|_1)
+    const size_t pl_bytes = sizeof(uint64_t) * 2 * (size_t)tiles * 2 * CGH_BLOCK, part_bytes = sizeof(uint64_t) * 4 * CGP_MAX_TILES;
     if (!sv->pl) {
-        // images: two tagged words per entry of r (whole tiles: idle lanes of the last tile read their own slot), four per
-        // workgroup for p.Ap and for (r.r, |r|_1); a fresh buffer carries tag 0, which no exchange uses
-        const size_t pl_bytes = sizeof(uint64_t) * 2 * (size_t)tiles * 2 * CGH_BLOCK, part_bytes = sizeof(uint64_t) * 4 * CGP_MAX_TILES;
         sv->pl = (uint64_t *)cgh_alloc(pl_bytes);
         sv->pa = (uint64_t *)cgh_alloc(part_bytes);
         sv->pb = (uint64_t *)cgh_alloc(part_bytes);
         if (!sv->pl || !sv->pa || !sv->pb) return CGH_ENOMEM;
+    }
+    // a cleared buffer carries tag 0, which no exchange uses; tags repeat after 2^18 solves, so the images are cleared
+    // whenever the epoch's higher bits differ from those of the last clearing (always the first time)
+    unsigned *period = sv->tag_period_home ? sv->tag_period_home : &sv->tag_period;
+    if (*period != sv->epoch >> CGP_EPOCH_BITS) {
         CGH_HIP(hipMemsetAsync(sv->pl, 0, pl_bytes, s));
         CGH_HIP(hipMemsetAsync(sv->pa, 0, part_bytes, s));
         CGH_HIP(hipMemsetAsync(sv->pb, 0, part_bytes, s));
+        *period = sv->epoch >> CGP_EPOCH_BITS;
     }
     const int first = sv->queued + 1;
-    if (sv->m->dict_state == 1)
+    if (sv->m->dict_state == 1 && sv->m->dict_mode == 1)
         launch_persistent<1>(sv, tiles, first, count, s);
     else
         launch_persistent<0>(sv, tiles, first, count, s);
     sv->queued += count;
+    ++g_persistent_launches;
     CGH_HIP(hipGetLastError());
     return CGH_OK;
 }
@@ -475,6 +490,9 @@ int cgh_solver_iterate(cgh_solver *sv, int count, int time_kernels)
 
 // 1 if this solver's next iterations run as one resident launch per batch (cg_persistent.h): after cgh_solver_start.
 int cgh_solver_is_resident(const cgh_solver *sv) { return sv && persistent_eligible(sv) ? 1 : 0; }
+
+// Tests: resident launches queued by this process so far.
+long long cgh_persistent_launches(void) { return g_persistent_launches; }
 
 // Tools: per-workgroup time stamps of the resident launch (8 long long per workgroup, 256 workgroups; NULL switches off).
 int cgh_persistent_set_trace(long long *d_trace)
@@ -681,16 +699,21 @@ int cgh_cg_solve(const cgh_matrix *m, const double *d_b, double *d_x, const cgh_
 // that pointer is handed to kernels and memsets.  Every call on a GPU shares that GPU's array and finds the previous
 // call's contents in it: what must start at zero (the converged flag) is cleared, everything else is written before
 // it is read.  Calls that overlap on one GPU (two host threads) would race on it.
-constexpr int64_t NOALLOC_MAX_ROWS = 1 << 20;  // 3 vectors of 2^20 doubles + partials + 1 MiB for the order-exact sums: 26.2 MB per GPU, held until the process ends
+constexpr int64_t NOALLOC_MAX_ROWS = 1 << 20;  // 3 vectors of 2^20 doubles + partials + 1 MiB for the order-exact sums + 2 MiB for the resident launch: 28.3 MB per GPU, held until the process ends
 constexpr size_t  NOALLOC_PART_A = (size_t)3 * NOALLOC_MAX_ROWS;
 constexpr size_t  NOALLOC_PART_B = NOALLOC_PART_A + CGH_MAX_PARTIALS;
 constexpr size_t  NOALLOC_DONE = NOALLOC_PART_B + 2 * CGH_MAX_PARTIALS;
 constexpr size_t  NOALLOC_XSUM = NOALLOC_DONE + 32;            // workspace of the order-exact sums (strict mode from 4096 rows on)
 constexpr size_t  NOALLOC_XSUM_DOUBLES = (size_t)1 << 17;      // 1 MiB; 2^20 rows need 803 840 bytes (cgh_xsum_device_bytes)
-constexpr size_t  NOALLOC_DOUBLES = NOALLOC_XSUM + NOALLOC_XSUM_DOUBLES;
+// images of the resident launch of small throughput-mode solves (cg_persistent.h): r of 256 tiles, the two arrays of partials
+constexpr size_t  NOALLOC_RL = NOALLOC_XSUM + NOALLOC_XSUM_DOUBLES;
+constexpr size_t  NOALLOC_RL_DOUBLES = (size_t)2 * CGP_MAX_TILES * 2 * CGH_BLOCK;  // 2 MiB
+constexpr size_t  NOALLOC_PA = NOALLOC_RL + NOALLOC_RL_DOUBLES, NOALLOC_PB = NOALLOC_PA + 4 * CGP_MAX_TILES;
+constexpr size_t  NOALLOC_DOUBLES = NOALLOC_PB + 4 * CGP_MAX_TILES;
 static_assert((NOALLOC_XSUM * sizeof(double)) % 256 == 0, "the sums' workspace starts on a 256-byte boundary");
 static __device__ __align__(256) double scratch[NOALLOC_DOUBLES];
 static double *g_scratch_ptr[64] = {nullptr};  // per device: each GPU holds its own copy of the array at its own address
+static unsigned g_scratch_tag_period[64];      // per device: when the resident launch's images in it were last cleared
 
 int cgh_noalloc_setup(int device)
 {
@@ -699,6 +722,7 @@ int cgh_noalloc_setup(int device)
     void *p = nullptr;
     CGH_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
     g_scratch_ptr[device] = (double *)p;
+    g_scratch_tag_period[device] = ~0u;
     return CGH_OK;
 }
 
@@ -750,6 +774,10 @@ extern "C" int cgh_cg_solve_noalloc(const cgh_matrix *m, const double *d_b, doub
     sv.hist = d_history;
     sv.vgrid = vec_grid(m->n);
     sv.no_alloc = true;
+    sv.pl = reinterpret_cast<uint64_t *>(ws + NOALLOC_RL);
+    sv.pa = reinterpret_cast<uint64_t *>(ws + NOALLOC_PA);
+    sv.pb = reinterpret_cast<uint64_t *>(ws + NOALLOC_PB);
+    sv.tag_period_home = &g_scratch_tag_period[g_cgh.device];
     int rc = cgh_solver_start(&sv, d_b, d_x, tol, strict);  // clears the converged flag, zeroes x
     if (rc) return rc;
     rc = enqueue_iterations(&sv, max_iter - 1, 0, false);    // cg.c:459: iter = 1 .. max_iter-1; frozen once converged

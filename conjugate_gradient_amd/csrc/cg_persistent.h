@@ -33,6 +33,14 @@ constexpr long long CGP_TIMEOUT_TICKS = 200000000ll;  // 2 s of the 100 MHz cons
 
 typedef int i2p_t __attribute__((ext_vector_type(2)));
 
+// Tag of iteration `it` (at most 8191: the history window holds 4096) of solve `epoch`: never 0, the value of a cleared
+// buffer.  18 bits of epoch: the host clears the buffers whenever the epoch's higher bits have changed since it last did.
+constexpr unsigned CGP_EPOCH_BITS = 18;
+__host__ __device__ inline unsigned cgp_tag(unsigned epoch, unsigned it)
+{
+    return 0x80000000u | ((epoch & ((1u << CGP_EPOCH_BITS) - 1u)) << 13) | (it & 0x1fffu);
+}
+
 // Tagged entries travel as ONE 16-byte access each: buffer_load / buffer_store_dwordx4 with the sc1 bit (agent scope:
 // stores written through, loads served below L1) through the raw-buffer builtins, so that the compiler keeps many in
 // flight and waits where the data is used.  (volatile accesses are completed one by one, s_waitcnt vmcnt(0) after
@@ -225,7 +233,7 @@ __global__ __launch_bounds__(CGH_BLOCK) void cg_persistent(int64_t n, const doub
         tprev = tnow;                         \
     }
     for (int it = first_iter; it < first_iter + count; ++it) {
-        const unsigned tg = cgh_ll_tag(epoch, (unsigned)it);
+        const unsigned tg = cgp_tag(epoch, (unsigned)it);
         // ---- Ap = A p (rows of this lane), the arithmetic of spmv_ell_r2
         double a0 = add_rn(0.0, mul_rn(dg.x, pv.x));
         double a1 = add_rn(0.0, mul_rn(dg.y, pv.y));

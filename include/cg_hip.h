@@ -122,6 +122,7 @@ int     cgh_config_pb(int span_bits, int64_t target_entries, int split, int orde
 int     cgh_config_persistent(int on);
 struct cgh_solver;
 int     cgh_solver_is_resident(const struct cgh_solver *sv);  /* after cgh_solver_start: 1 if its iterations take that path */
+long long cgh_persistent_launches(void);                      /* tests: resident launches queued by this process so far */
 /* Tools (tools/quick_persistent.py): the resident launch leaves, per workgroup, the ticks (100 MHz) its first lane spent in
  * five sections of the iteration, summed over the launch, in d_trace[8 w + k] (device memory, 256 x 8 values); NULL = off. */
 int     cgh_persistent_set_trace(long long *d_trace);
@@ -197,8 +198,8 @@ int cgh_cg_solve(const cgh_matrix *m, const double *d_b, double *d_x,
  * hipMalloc: code under HIP graph capture, tight serving loops that solve one small system after another, harnesses that
  * forbid allocation.  It is cgh_cg_solve (same kernels, same launch shapes, same bits) with the solver's workspace
  * (r, p, A p, the per-workgroup partials, the converged flag) in a __device__ array built into the library: 25.2 MB
- * that every GPU the library runs on holds until the process ends (26.2 MB with the workspace of the order-exact sums that
- * strict = 1 uses from 4096 rows on).  Limit: at most 2^20 = 1048576 rows, and a matrix with rows -- anything else is
+ * that every GPU the library runs on holds until the process ends (28.3 MB with the workspace of the order-exact sums that
+ * strict = 1 uses from 4096 rows on and the images of the resident launch that strict = 0 takes up to 131 072 rows).  Limit: at most 2^20 = 1048576 rows, and a matrix with rows -- anything else is
  * refused with CGH_EINVAL and a message.  Asynchronous: all max_iter-1 iterations are queued on the library's stream
  * (the device freezes x, r, p at the converging iteration) and the call returns; after cgh_sync() d_x holds the
  * solution, d_history[4*k..] = { l1norm(r)/2, r.r, alpha, beta } for k = 0 .. converging iteration (4*max_iter doubles,

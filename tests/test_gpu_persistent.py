@@ -23,7 +23,11 @@ def _solve(cga, A, b_host, n, on, **kw):
     cga.check(cga.lib().cgh_config_persistent(on))
     b = cga.DeviceVector.from_host(b_host)
     x = cga.DeviceVector.from_host(np.full(n, 3.0))   # the solver must zero it (cg.c:433)
+    before = cga.lib().cgh_persistent_launches()
     rep, hist = cga.cg_solve(A, b, x, strict=0, **kw)
+    took = cga.lib().cgh_persistent_launches() - before
+    # the path under test really is the one that ran (rows wider than 8 slots keep three launches either way)
+    assert (took > 0) == bool(on and A.K <= 8), (on, A.K, took)
     return rep, hist, x.to_host()
 
 
@@ -135,3 +139,18 @@ def test_unstructured_columns_int32(cga):
     rep1, h1, x1 = _solve(cga, A, s["source"], n, 1, fixed_iters=300)
     assert A.dict_offsets <= 0            # int32 columns
     assert same_bits_nan(h1, h0) and np.array_equal(bits(x1), bits(x0))
+
+
+def test_history_window_slides_under_the_resident_launch(cga):
+    """A solve longer than the device's history window (4096 iterations) continues in a fresh window: iteration numbers --
+    and with them the tags of the exchanged words -- start again at 1 inside the same solve.  9000 iterations of both paths."""
+    nx, ny, nz = 64, 64, 31
+    n = nx * ny * nz
+    b = cga.DeviceVector(n)
+    A = cga.Matrix.poisson(nx, ny, nz, 7, 0x5EED0001, cga.LAYOUT_ELL, b)
+    bh = b.to_host()
+    rep0, h0, x0 = _solve(cga, A, bh, n, 0, fixed_iters=9000)
+    rep1, h1, x1 = _solve(cga, A, bh, n, 1, fixed_iters=9000)
+    assert rep0.iterations == rep1.iterations == 9000
+    assert same_bits_nan(h1, h0) and same_bits_nan(x1, x0)
+    assert np.isfinite(h1[:4200, 0]).all()        # well past the first slide of the window

@@ -38,7 +38,7 @@ def _noalloc(cga, A, b, n, max_iter, tol, strict, capture=False, check_free=True
     hist_d = cga.DeviceVector.from_host(np.full(4 * max_iter, -3.0))
     status = cga.DeviceVector.from_host(np.full(4, -1, dtype=np.int32))
     cga.check(L.cgh_sync())
-    calls0, free0 = L.cgh_alloc_calls(), _free_bytes(cga)
+    calls0, free0, resident0 = L.cgh_alloc_calls(), _free_bytes(cga), L.cgh_persistent_launches()
     if capture:
         cga.check(L.cgh_capture_begin(), "cgh_capture_begin")
     rc = L.cgh_cg_solve_noalloc(A.h, b.ptr, x2.ptr, max_iter, tol, strict, hist_d.ptr, status.ptr)
@@ -50,6 +50,11 @@ def _noalloc(cga, A, b, n, max_iter, tol, strict, capture=False, check_free=True
     cga.check(rc, "cgh_cg_solve_noalloc")
     cga.check(L.cgh_sync())
     assert calls1 == calls0, "cgh_cg_solve_noalloc called cgh_alloc %d times" % (calls1 - calls0)
+    # small throughput-mode ELL solves take the ONE resident launch (its tagged images are part of the built-in array) --
+    # except under capture, where a replay would meet its own tags from the replay before
+    resident = L.cgh_persistent_launches() - resident0
+    small_ell = strict == 0 and cga.lib().cgh_matrix_layout(A.h) == cga.LAYOUT_ELL and n <= 131072 and A.K <= 8
+    assert resident == (1 if small_ell and not capture else 0), (resident, small_ell, capture)
     if not capture and check_free:
         assert _free_bytes(cga) == free0, "free device memory changed across cgh_cg_solve_noalloc"
     return x2, hist_d.to_host().reshape(max_iter, 4), int(status.to_host()[0])
