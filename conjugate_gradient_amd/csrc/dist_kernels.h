@@ -124,7 +124,7 @@ __device__ __forceinline__ void push_pair(const cgh_pushes &P, int64_t row0, dou
         if (k < -1 || k >= P.cnt[j]) continue;
         uint64_t *lo = P.dst[j] + k, *hi = lo + P.plane[j];
         if (k >= 0 && k + 1 < P.cnt[j] && ((reinterpret_cast<uintptr_t>(lo) | reinterpret_cast<uintptr_t>(hi)) & 15u) == 0) {
-            ll_store_pair(lo, hi, v0, v1, P.tag);
+            ll_store_pair(P.dst[j], k, P.plane[j] + k, v0, v1, P.tag);
         } else {
             if (k >= 0) ll_store(lo, hi, v0, P.tag);
             if (k + 1 < P.cnt[j]) ll_store(lo + 1, hi + 1, v1, P.tag);

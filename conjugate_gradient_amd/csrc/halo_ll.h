@@ -77,19 +77,27 @@ __device__ __forceinline__ void ll_store(uint64_t *lo, uint64_t *hi, double v, u
     __hip_atomic_store(hi, t | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-// Two consecutive entries, lo and hi 16-byte aligned: two 16-byte stores with the cache bits of a system-scope store
-// (a volatile access compiles to `... sc0 sc1`), so that a wave writes whole, contiguous lines across xGMI.  Every
-// aligned 64-bit word still arrives whole, which is all the tags need.
-__device__ __forceinline__ void ll_store_pair(uint64_t *lo, uint64_t *hi, double v0, double v1, unsigned tag)
+// Two consecutive entries, at words lo_word and hi_word (both even) of `base` (the same in every lane: a neighbour's
+// deposit slot): two 16-byte stores with the cache bits of a system-scope store (sc0 sc1: written through), so that a
+// wave writes whole, contiguous lines across xGMI.  Every aligned 64-bit word still arrives whole, which is all the tags
+// need.  Through the raw-buffer builtin, NOT a volatile access: the compiler completes every volatile access on its own
+// (s_waitcnt vmcnt(0) after each store -- a round trip over xGMI per store for the lanes that push, found in round 3),
+// and a volatile cast also loses the address space (flat_ instead of global_ instructions).
+typedef unsigned cgh_u4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void ll_store_pair(uint64_t *base, int64_t lo_word, int64_t hi_word, double v0, double v1, unsigned tag)
 {
-    const uint64_t b0 = (uint64_t)__double_as_longlong(v0), b1 = (uint64_t)__double_as_longlong(v1), t = (uint64_t)tag << 32;
-    cgh_ull2       l, h;
-    l.x = t | (b0 & 0xffffffffull);
-    l.y = t | (b1 & 0xffffffffull);
-    h.x = t | (b0 >> 32);
-    h.y = t | (b1 >> 32);
-    *reinterpret_cast<volatile cgh_ull2 *>(lo) = l;
-    *reinterpret_cast<volatile cgh_ull2 *>(hi) = h;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(base, 0, -1, 0x00020000);
+    cgh_u4                       l, h;
+    l.x = (unsigned)__double2loint(v0);
+    l.y = tag;
+    l.z = (unsigned)__double2loint(v1);
+    l.w = tag;
+    h.x = (unsigned)__double2hiint(v0);
+    h.y = tag;
+    h.z = (unsigned)__double2hiint(v1);
+    h.w = tag;
+    __builtin_amdgcn_raw_buffer_store_b128(l, rs, (unsigned)(lo_word * 8), 0, 17 /* sc0 sc1 */);
+    __builtin_amdgcn_raw_buffer_store_b128(h, rs, (unsigned)(hi_word * 8), 0, 17);
 }
 
 // Wait for the words at lo and hi to carry `tag`; NaN (and *err = 1) after 10 s, or at once if an earlier wait timed out.
