@@ -206,8 +206,13 @@ __global__ __launch_bounds__(CGH_BLOCK) void cg_persistent(int64_t n, const doub
     }
     double   rr_prev = hist[(size_t)(first_iter - 1) * HIST + 1];
     int      conv_at = 0, last = first_iter - 1;
-    // entry i of the image of r = words 2 i, 2 i + 1 of rl; workgroup w's partials = entries 2 w, 2 w + 1 of pa / pb
+    // The image of r holds the even rows, then the odd rows (entry of row i at (i & 1) half + (i >> 1)): a lane's two rows
+    // have neighbours of equal parity in a banded matrix, so each of its gathers is then one contiguous run of 16-byte
+    // entries over the wave -- every 128-byte line is fetched once, not by two instructions of half its entries each.
+    // Workgroup w's partials = entries 2 w, 2 w + 1 of pa / pb.
     const int                    tiles = (int)((pairs + CGH_BLOCK - 1) / CGH_BLOCK);
+    const unsigned               half = (unsigned)tiles * CGH_BLOCK;
+    auto                         slot_of = [half](int row) { return ((unsigned)row & 1u) * half + ((unsigned)row >> 1); };
     const __amdgpu_buffer_rsrc_t RL = cgp_rsrc(rl, (size_t)tiles * 2 * CGH_BLOCK * 16), PA = cgp_rsrc(pa, (size_t)CGP_MAX_TILES * 32),
                                  PB = cgp_rsrc(pb, (size_t)CGP_MAX_TILES * 32);
 
@@ -272,7 +277,10 @@ __global__ __launch_bounds__(CGH_BLOCK) void cg_persistent(int64_t n, const doub
         rr += rn.x * rn.x + rn.y * rn.y;
         l1 += fabs(rn.x) + fabs(rn.y);
         // the new r of this tile for the lanes elsewhere that gather it, then the tile's partials
-        if (live) cgp_store2(RL, (unsigned)i0, rn.x, rn.y, tg);
+        if (live) {
+            __builtin_amdgcn_raw_buffer_store_b128(cgp_entry(rn.x, tg), RL, slot_of((int)i0) * 16u, 0, CGP_SC1);
+            __builtin_amdgcn_raw_buffer_store_b128(cgp_entry(rn.y, tg), RL, slot_of((int)i0 + 1) * 16u, 0, CGP_SC1);
+        }
         double trr = rr, tl1 = l1;
         cgp_block_sum2(trr, tl1, lds, flip);
         if (tid == 0) cgp_store2(PB, 2u * w, trr, tl1, tg);
@@ -293,8 +301,8 @@ __global__ __launch_bounds__(CGH_BLOCK) void cg_persistent(int64_t n, const doub
             const bool o0 = c[s].x >= 0 && (unsigned)(c[s].x - tile0) >= 2u * CGH_BLOCK;
             const bool o1 = c[s].y >= 0 && (unsigned)(c[s].y - tile0) >= 2u * CGH_BLOCK;
             e0[s] = e1[s] = none;
-            if (o0) e0[s] = cgp_load(RL, (unsigned)c[s].x);
-            if (o1) e1[s] = cgp_load(RL, (unsigned)c[s].y);
+            if (o0) e0[s] = cgp_load(RL, slot_of(c[s].x));
+            if (o1) e1[s] = cgp_load(RL, slot_of(c[s].y));
         }
         if (tid < G) {
             prr = cgp_await(PB, 2u * tid, f0, tg, err);
@@ -305,8 +313,8 @@ __global__ __launch_bounds__(CGH_BLOCK) void cg_persistent(int64_t n, const doub
         for (int s = 0; s < KT; ++s) {
             const bool o0 = c[s].x >= 0 && (unsigned)(c[s].x - tile0) >= 2u * CGH_BLOCK;
             const bool o1 = c[s].y >= 0 && (unsigned)(c[s].y - tile0) >= 2u * CGH_BLOCK;
-            gr0[s] = o0 ? cgp_await(RL, (unsigned)c[s].x, e0[s], tg, err) : 0.0;
-            gr1[s] = o1 ? cgp_await(RL, (unsigned)c[s].y, e1[s], tg, err) : 0.0;
+            gr0[s] = o0 ? cgp_await(RL, slot_of(c[s].x), e0[s], tg, err) : 0.0;
+            gr1[s] = o1 ? cgp_await(RL, slot_of(c[s].y), e1[s], tg, err) : 0.0;
         }
         CGP_STAMP(3)
         double rrn = 0.0, l1n = 0.0;
