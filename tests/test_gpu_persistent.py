@@ -154,3 +154,31 @@ def test_history_window_slides_under_the_resident_launch(cga):
     assert rep0.iterations == rep1.iterations == 9000
     assert same_bits_nan(h1, h0) and same_bits_nan(x1, x0)
     assert np.isfinite(h1[:4200, 0]).all()        # well past the first slide of the window
+
+
+@pytest.mark.parametrize("K", [1, 2, 3, 4, 5, 6, 7, 8])
+@pytest.mark.parametrize("dict_on", [1, 0])
+def test_every_width_with_and_without_coded_columns(cga, monkeypatch, K, dict_on):
+    """Every compile-time width of the resident launch, with dictionary-coded and with int32 columns: banded matrices with
+    K off-diagonals at mixed distances (inside the tile, in the next tile, many tiles away), symmetric pattern where K is even.
+    30 iterations, both paths, same bits (the two paths share no reduction code: any difference in order would show)."""
+    from gpu_common import setknob
+    setknob(monkeypatch, "CGH_ELL_DICT", dict_on)
+    n = 9000                                     # 18 tiles, ragged last one
+    offs = [1, -1, 40, -40, 700, -700, 4100, -4100][:K]
+    rng = np.random.default_rng(100 + K)
+    cols = np.full((K, n), -1, dtype=np.int32)
+    vals = np.zeros((K, n))
+    i = np.arange(n)
+    for s, o in enumerate(offs):
+        ok = (i + o >= 0) & (i + o < n)
+        cols[s, ok] = (i + o)[ok]
+        vals[s, ok] = -rng.random(ok.sum()) * 0.5
+    diag = K + 1.0 + rng.random(n)
+    bh = rng.standard_normal(n)
+    A = cga.Matrix.from_ell(n, K, diag, vals.reshape(-1), cols.reshape(-1))
+    rep0, h0, x0 = _solve(cga, A, bh, n, 0, fixed_iters=30)
+    rep1, h1, x1 = _solve(cga, A, bh, n, 1, fixed_iters=30)
+    assert (A.dict_offsets > 0) == bool(dict_on)
+    assert same_bits_nan(h1, h0) and same_bits_nan(x1, x0)
+    assert np.isfinite(h1[1:5]).all() and np.isfinite(h1[:5, :2]).all()
