@@ -15,6 +15,7 @@
 // DOT=true additionally leaves sum_i x[i]*y[i] of the workgroup's rows in partials[blockIdx.x]
 // (CG: x is p, y is Ap; saves a full re-read of p and Ap).
 #include <algorithm>
+#include <mutex>
 #include <vector>
 
 #include "cgh_internal.h"
@@ -378,10 +379,17 @@ __global__ __launch_bounds__(256) void dict_encode_packed(int64_t n, int K, cons
     }
 }
 
-// Build m->cols8 / m->off_tab if the matrix has at most 255 distinct diagonals.  Synchronises the stream.
+std::mutex g_dict_mutex;
+
+// Build m->cols8 / m->off_tab if the matrix has at most 255 distinct diagonals.  Synchronises the stream.  Called under
+// g_dict_mutex; dict_state becomes 1 (in use) only after everything it guards is in place, 2 (not applicable) otherwise.
 void ell_dict_try_build(const cgh_matrix *m, hipStream_t s)
 {
-    m->dict_state = 2;
+    struct publish {  // whatever path leaves this function: "tried" at the very end
+        const cgh_matrix *m;
+        int               state = 2;
+        ~publish() { __atomic_store_n(&m->dict_state, state, __ATOMIC_RELEASE); }
+    } done{m};
     const int     enabled = g_cfg.ell_dict < 0 ? 1 : g_cfg.ell_dict;
     const int64_t total = m->n * (int64_t)m->K;
     if (!enabled || m->K <= 0 || total < 2) return;
@@ -426,7 +434,7 @@ void ell_dict_try_build(const cgh_matrix *m, hipStream_t s)
     }
     m->n_offsets = count;
     m->dict_mode = mode;
-    m->dict_state = 1;
+    done.state = 1;
 }
 
 } // namespace
@@ -515,10 +523,15 @@ int cgh_launch_spmv_ell_range2(const cgh_matrix *m, const double *x, double *y, 
         return rc;
     }
     if (ell_vector_path(m, x, y) && rb % 2 == 0 && re % 2 == 0 && rb2 % 2 == 0 && re2 % 2 == 0) {
-        if (m->dict_state == 0 && !(opts && opts->no_alloc)) {
+        if (__atomic_load_n(&m->dict_state, __ATOMIC_ACQUIRE) == 0 && !(opts && opts->no_alloc)) {
             hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
             (void)hipStreamIsCapturing(s, &cap);
-            if (cap == hipStreamCaptureStatusNone) ell_dict_try_build(m, s);
+            if (cap == hipStreamCaptureStatusNone) {
+                // the one place a launch path changes a (logically const) matrix: once, under a lock; the state word is
+                // published last, so a thread that does not take the lock sees either "not built" or a complete dictionary
+                std::lock_guard<std::mutex> guard(g_dict_mutex);
+                if (m->dict_state == 0) ell_dict_try_build(m, s);
+            }
         }
         // strict mode's per-cell sums of x.y instead of per-workgroup partials
         if (cell_sums != nullptr && dot_partials == nullptr && rb == 0 && re == m->n && re2 <= rb2 && m->n % 128 == 0) {
@@ -612,7 +625,10 @@ int cgh_launch_spmv_ell_halo(const cgh_matrix *m, const double *x, double *y, do
     if (grid_out) *grid_out = rows > 0 ? grid : 0;
     if (!cgh_spmv_ell_halo_capable(m, x, y, rb, re, rb2, re2) || !dot_partials) return CGH_EINVAL;
     if (rows <= 0) return CGH_OK;
-    if (m->dict_state == 0) ell_dict_try_build(m, s);
+    if (__atomic_load_n(&m->dict_state, __ATOMIC_ACQUIRE) == 0) {
+        std::lock_guard<std::mutex> guard(g_dict_mutex);
+        if (m->dict_state == 0) ell_dict_try_build(m, s);
+    }
 #define CGH_ELL_HALO_LAUNCH(V)                                                                                                 \
     if (m->dict_state == 1 && m->dict_mode == 2)                                                                               \
         launch_r2<1, V, 2, 1>(m->K, grid, s, m->n, m->diag, m->vals, m->cols8, m->off_tab, x, y, dot_partials, done, rb, re, rb2, re2, \
