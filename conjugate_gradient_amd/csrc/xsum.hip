@@ -1289,6 +1289,36 @@ __device__ double xr_sum(xr_shared &S, int slot, int64_t n, const double *__rest
     const unsigned ready_at = direct ? 4u : XS_BATCH_READY;
     double         s = 0.0;
     int            cur = 0;
+    int            head = 0;  // cells at the front of the sum that the walk has already added element by element
+    if constexpr (FLAT) {
+        // Few cells: the launch is short, the walk is its critical path -- and until the first batch's summaries are in
+        // memory (6.6 us after the start at 32 768 elements) the walk has nothing to do, while the front of a sum is where it
+        // is slowest (the running sum doubles every few elements: the first cells are the ones that end up being added
+        // element by element anyway).  So the walking wave starts on them at once, one cell per 0.7 us with the next
+        // cell's elements in flight, and hands over to the summaries as soon as the first batch is ready; the summaries of
+        // the cells it got through are then simply not used (xs_batch starts behind them).
+        const int ccnt0 = (int)(ncells < XS_GROUP ? ncells : XS_GROUP);
+        double    e0, e1;
+        xs_cell_terms<KIND>(slot, n, a, b, c, 0, e0, e1);
+        while (head < ccnt0) {
+            unsigned f = 0;
+            if (lane == 0) f = __hip_atomic_load(ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // examined behind the chain
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();  // the previous cell's reads are over
+            *reinterpret_cast<double2 *>(S.stage + 2 * lane) = make_double2(e0, e1);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            double n0 = 0.0, n1 = 0.0;
+            if (head + 1 < ccnt0) xs_cell_terms<KIND>(slot, n, a, b, c, head + 1, n0, n1);
+            s = xs_chain(s, S.stage);
+            ++head;
+            if ((unsigned)__builtin_amdgcn_readfirstlane((int)f) >= ready_at) break;
+            e0 = n0;
+            e1 = n1;
+        }
+        xs_compiler_acquire();
+    }
     long long t0 = wall_clock64();
     while (cur < nb) {
         // the batches from `cur` on whose summaries are in memory: a prefix of up to 64, taken together
@@ -1308,8 +1338,10 @@ __device__ double xr_sum(xr_shared &S, int slot, int64_t n, const double *__rest
         }
         xs_summary Bq = xs_identity();
         if (lane < m) {
-            if (direct) Bq = xs_regular(0, 0, 0, 0, 0, true);  // "does not apply": every batch is entered
-            else Bq = xs_load_agent(batches + cur + lane);
+            if (direct || (cur == 0 && lane == 0 && head > 0))
+                Bq = xs_regular(0, 0, 0, 0, 0, true);  // "does not apply": every batch is entered / the walk is inside batch 0 already
+            else
+                Bq = xs_load_agent(batches + cur + lane);
             __hip_atomic_store(ready + cur + lane, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // zero for the next launch
         }
         for (int q = 0; q < m; ++q) XR_STAMP(8, cur + q);
@@ -1325,7 +1357,7 @@ __device__ double xr_sum(xr_shared &S, int slot, int64_t n, const double *__rest
                 xs_summary    Cq = xs_identity();
                 if (lane < ccnt) Cq = xs_load_agent(cells + c0 + lane);
                 const int64_t Cinc = xs_scan(Cq, ccnt);
-                int           cstart = 0;
+                int           cstart = bb == 0 ? head : 0;  // (the first `head` cells of the sum are in s already)
                 while (cstart < ccnt) {
                     const int cf = xs_batch(Cq, Cinc, cstart, ccnt, s);
                     if (cf >= ccnt) break;
