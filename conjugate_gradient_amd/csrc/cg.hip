@@ -110,9 +110,9 @@ struct cgh_solver {
 
 // The strict-mode sums of the solver (modes: see seq_sums): parallel order-exact sums for long vectors, one lane otherwise.
 static int strict_sums(cgh_solver *sv, const double *a, const double *b, const double *c, int mode, int iter, hipStream_t s,
-                       bool presummed = false, double *xu_x = nullptr, const double *xu_p = nullptr, bool *xu_taken = nullptr)
+                       bool presummed = false, double *xu_x = nullptr, const double *xu_p = nullptr, int *xu_taken = nullptr)
 {
-    if (xu_taken) *xu_taken = false;
+    if (xu_taken) *xu_taken = 0;
     if (sv->xs)
         return cgh_xsum_launch(sv->xs, sv->n, a, b, c, mode, sv->hist, iter, sv->tol, sv->done, nullptr, s, presummed, xu_x, xu_p, xu_taken);
     hipLaunchKernelGGL(seq_sums, dim3(1), dim3(CGH_BLOCK), 0, s, sv->n, a, b, c, mode, sv->hist, iter, sv->tol, sv->done,
@@ -399,22 +399,28 @@ static int enqueue_iterations(cgh_solver *sv, int count, int time_kernels, bool 
             hipLaunchKernelGGL(pcg_update_xp, dim3(vg), dim3(CGH_BLOCK), 0, s, n, d_x, (const double *)dr, dp, dg,
                                (const double *)dB, vg, dh, iter, tol, dd);
         } else if (sv->strict) {
-            rc = strict_sums(sv, dp, dAp, nullptr, 1, iter, s, pAp_presummed);
+            // (few cells: the launch of the sums of p.Ap keeps its workgroups for r -= alpha Ap behind the verdict, xs_tail)
+            int r_done = 0;
+            rc = strict_sums(sv, dp, dAp, nullptr, 1, iter, s, pAp_presummed, device_iter || serp ? nullptr : dr, nullptr, &r_done);
             if (rc) return rc;
-            // with the parallel sums, the r update also leaves their per-cell approximate sums (one sweep over r less)
-            // (whole groups of the sums' hierarchy per workgroup, so that the group sums come out as well -- unless the sweep
-            // direction is reversed, or the sums are so short that their launch adds up the cell sums itself)
-            double *gsums = rev2 || cgh_xsum_cells(sv->xs) <= 4096 ? nullptr : cgh_xsum_groupsums(sv->xs);
-            hipLaunchKernelGGL((cg_update_r<1, 3>), dim3(vg), dim3(CGH_BLOCK), 0, s, n, dr, (const double *)dAp,
-                               (const double *)dA, gridA, dB, dh, iter, (const int *)dd, rev2, (const double *)nullptr,
-                               cgh_xsum_cellsums(sv->xs), cgh_xsum_cells(sv->xs), gsums);
-            if (gsums) cgh_xsum_groups_written(sv->xs);
-            // ... and the launch of the sums of r may take x += alpha p along (xsum.hip, xs_fused): then K3 only updates p
-            bool x_done = false;
+            if (r_done != 2) {
+                // with the parallel sums, the r update also leaves their per-cell approximate sums (one sweep over r less)
+                // (whole groups of the sums' hierarchy per workgroup, so that the group sums come out as well -- unless the sweep
+                // direction is reversed, or the sums are so short that their launch adds up the cell sums itself)
+                double *gsums = rev2 || cgh_xsum_cells(sv->xs) <= 4096 ? nullptr : cgh_xsum_groupsums(sv->xs);
+                hipLaunchKernelGGL((cg_update_r<1, 3>), dim3(vg), dim3(CGH_BLOCK), 0, s, n, dr, (const double *)dAp,
+                                   (const double *)dA, gridA, dB, dh, iter, (const int *)dd, rev2, (const double *)nullptr,
+                                   cgh_xsum_cellsums(sv->xs), cgh_xsum_cells(sv->xs), gsums);
+                if (gsums) cgh_xsum_groups_written(sv->xs);
+            }
+            // ... and the launch of the sums of r may take x += alpha p along (xsum.hip, xs_fused): then K3 only updates p --
+            // or, with few cells, both updates behind its verdict (xs_tail): then there is no K3
+            int x_done = 0;
             rc = strict_sums(sv, dr, dr, dr, 2, iter, s, sv->xs != nullptr, d_x, dp, &x_done);
             if (rc) return rc;
-            hipLaunchKernelGGL((cg_update_xp<1, 3>), dim3(vg), dim3(CGH_BLOCK), 0, s, n, x_done ? (double *)nullptr : d_x, (const double *)dr, dp,
-                               (const double *)dB, vg, dh, iter, tol, dd, rev1, (const double *)nullptr);
+            if (x_done != 2)
+                hipLaunchKernelGGL((cg_update_xp<1, 3>), dim3(vg), dim3(CGH_BLOCK), 0, s, n, x_done ? (double *)nullptr : d_x, (const double *)dr, dp,
+                                   (const double *)dB, vg, dh, iter, tol, dd, rev1, (const double *)nullptr);
         } else {
             // non-temporal loads + x store (3) unless the working set is within twice the Infinity Cache (0): see cgh_fits_llc
             const int vv_env = g_cfg.vec_variant >= 0 ? g_cfg.vec_variant & 15 : -1;

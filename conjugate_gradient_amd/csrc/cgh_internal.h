@@ -123,6 +123,7 @@ struct cgh_config {
     int64_t xsum_min_rows = 4096; // CGH_XSUM_MIN_ROWS: shortest vector taking the order-exact parallel sums (-1 never)
     int    xsum_xupd = 1;       // CGH_XSUM_XUPD: the fused launch of the sums of r also carries x += alpha p
     int    xsum_fused = 1;      // CGH_XSUM_FUSED: summaries and walk of the order-exact sums in one launch (0: two launches)
+    int    xsum_tail = 1;       // CGH_XSUM_TAIL: few cells: the vector update behind a sum's verdict stays in the sum's launch
     int    serpentine = 0;      // CGH_SERPENTINE: alternate the sweep direction of the iteration's kernels
     int    vec_variant = -1;    // CGH_VEC_VARIANT: cache-hint variant of the vector kernels, -1 = by working-set size
     int    graph = 0;           // CGH_GRAPH: replay batches of iterations from HIP graphs
@@ -197,11 +198,13 @@ cgh_xsum *cgh_xsum_place(void *obj, size_t obj_bytes, int64_t n, void *dev, size
 // a, b, c must either be (a, b, NULL), (NULL, NULL, c) or (v, v, v).
 // presummed: the approximate per-cell sums (128 elements each; slot 0 = dot at [0, cells), slot 1 = l1 at [cells, 2 cells))
 // were already written to cgh_xsum_cellsums() by the kernel that produced the vector; else a sweep computes them.
-// xu_x / xu_p (mode 2, a == b == c only): the launch may also do x += alpha p of the iteration in flight (alpha from the
-// history); *xu_taken says whether it did -- the caller's cg_update_xp then leaves x alone.
+// xu_x / xu_p: vector updates the launch may take along.  Mode 2 (a == b == c = r), xu_x = x, xu_p = p: x += alpha p of the
+// iteration in flight (alpha from the history) -- *xu_taken = 1, the caller's cg_update_xp then leaves x alone; with few cells
+// also p = r + beta p behind the verdict (*xu_taken = 2: nothing is left for cg_update_xp).  Mode 1 (a = p, b = Ap), xu_x = r,
+// few cells: r -= alpha Ap behind the verdict, with the per-cell sums of the new r (*xu_taken = 2: no cg_update_r).
 int cgh_xsum_launch(cgh_xsum *w, int64_t n, const double *a, const double *b, const double *c, int mode, double *hist,
                     int iter, double tol, int *done, double *out, hipStream_t s, bool presummed = false, double *xu_x = nullptr,
-                    const double *xu_p = nullptr, bool *xu_taken = nullptr);
+                    const double *xu_p = nullptr, int *xu_taken = nullptr);
 // a vector spread over several ranks: each rank's part in turn (s_in -> s_out, device), then the verdict on every rank
 int cgh_xsum_launch_part(cgh_xsum *w, int64_t n, const double *a, const double *b, const double *c, const double *s_in,
                          double *s_out, const int *done, hipStream_t s, bool presummed);

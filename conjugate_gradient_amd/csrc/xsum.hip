@@ -32,6 +32,8 @@ struct cgh_xsum {
     unsigned   *ready = nullptr;     // [2][batches of 64 groups]: groups summarised so far in the running fused launch (zero between launches)
     xs_summary *batches = nullptr;   // [2][batches]: the join of each batch's group summaries (fused launch)
     unsigned   *head = nullptr;      // [2]: workgroups of the head group counted so far (fused launch, group level; zero between launches)
+    unsigned long long *tail = nullptr;  // [8] tagged words: the verdict of a fused launch of few cells for the workgroups that stay on for the vector update (xs_tail)
+    unsigned    tail_seq = 0;        // launches with such a tail so far: their tag
     bool        owns = true;         // false: object and arrays live in storage of the caller's (cgh_xsum_place)
     bool        groups_presummed = false;  // the producer of the vector also left the group sums (consumed by the next launch)
 };
@@ -1429,6 +1431,119 @@ __device__ __forceinline__ void xs_update_x(int64_t n, double *__restrict__ x, c
     if ((n & 1) && e1 == n && e0 < n && threadIdx.x == 0) x[n - 1] = madd_rn(x[n - 1], alpha, p[n - 1]);
 }
 
+// ---- Few cells: the vector update that consumes the sums' verdict stays in the launch.
+// At these sizes (<= 2048 cells) a strict CG iteration is five short launches, and the two vector updates between the sums
+// (r -= alpha Ap behind p.Ap; x += alpha p, p = r + beta p behind the sums of r) are ~4.7 us each although they move
+// almost nothing.  Every summarising workgroup is resident anyway, so it stays on after its 16 cells: it loads its rows
+// of the operands, waits for the driver's verdict -- alpha, or (beta, converged), as tagged words, two 64-bit words per
+// double as in halo_ll.h -- and updates its 2048 rows; behind p.Ap it also leaves the approximate per-cell sums of the
+// new r that the next launch predicts its binades from (as cg_update_r does).  Same arithmetic as cg_update_r /
+// cg_update_xp (madd_rn), so the same bits.  Nothing waits for these workgroups; their wait gives up after 2 s (NaN).
+__device__ __forceinline__ void xs_tail_publish(unsigned long long *box, unsigned tag, double v0, unsigned flag)
+{
+    const unsigned long long b0 = (unsigned long long)__double_as_longlong(v0), t = (unsigned long long)tag << 32;
+    __hip_atomic_store(box + 0, t | (b0 & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(box + 1, t | (b0 >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(box + 2, t | flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// every lane of the calling wave gets (v0, flag); false after the timeout
+__device__ __forceinline__ bool xs_tail_await(const unsigned long long *box, unsigned tag, double &v0, unsigned &flag)
+{
+    unsigned long long w0 = 0, w1 = 0, w2 = 0;
+    const long long    t0 = wall_clock64();
+    for (unsigned spin = 0;; ++spin) {
+        w0 = __hip_atomic_load(box + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        w1 = __hip_atomic_load(box + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        w2 = __hip_atomic_load(box + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((unsigned)(w0 >> 32) == tag && (unsigned)(w1 >> 32) == tag && (unsigned)(w2 >> 32) == tag) break;
+        if ((spin & 255u) == 255u && wall_clock64() - t0 > XR_PATIENCE) {
+            v0 = __builtin_nan("");
+            flag = 0;
+            return false;
+        }
+        __builtin_amdgcn_s_sleep(2);
+    }
+    v0 = __longlong_as_double((long long)((w1 << 32) | (w0 & 0xffffffffull)));
+    flag = (unsigned)w2;
+    return true;
+}
+
+// the rows of summarising workgroup `sb` of a launch of few cells: 16 cells, four per wave, one row pair per lane and cell
+template <int KIND>
+__device__ __forceinline__ void xs_tail(unsigned sb, int64_t n, const double *__restrict__ a, const double *__restrict__ b, int64_t ncells,
+                                        double *__restrict__ cellsum, const unsigned long long *box, unsigned tag, double *upd,
+                                        double *upd_p, const double *hist, int iter)
+{
+    const int     lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t c0 = (int64_t)(sb >> 2) * XS_GROUP + (int64_t)(sb & 3) * 16 + wave * 4;
+    double2       u[4], v[4], w[4];
+    bool          whole[4], any[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int64_t i = (c0 + q) * XS_CELL + 2 * lane;
+        whole[q] = i + 1 < n;
+        any[q] = i < n;
+        u[q] = v[q] = w[q] = make_double2(0.0, 0.0);
+        if constexpr (KIND == XS_DOT) {  // behind p.Ap (a = p, b = Ap): r -= alpha Ap
+            if (whole[q]) {
+                u[q] = *reinterpret_cast<const double2 *>(upd + i);
+                v[q] = *reinterpret_cast<const double2 *>(b + i);
+            } else if (any[q]) {
+                u[q].x = upd[i];
+                v[q].x = b[i];
+            }
+        } else {  // behind the sums of r (a = r): x += alpha p; p = r + beta p
+            if (whole[q]) {
+                u[q] = *reinterpret_cast<const double2 *>(upd + i);
+                v[q] = *reinterpret_cast<const double2 *>(upd_p + i);
+                w[q] = *reinterpret_cast<const double2 *>(a + i);
+            } else if (any[q]) {
+                u[q].x = upd[i];
+                v[q].x = upd_p[i];
+                w[q].x = a[i];
+            }
+        }
+    }
+    double   verdict;
+    unsigned flag;
+    xs_tail_await(box, tag, verdict, flag);
+    if constexpr (KIND == XS_DOT) {
+        const double nalpha = -verdict;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int64_t i = (c0 + q) * XS_CELL + 2 * lane;
+            double2       rn = make_double2(0.0, 0.0);
+            if (any[q]) rn.x = madd_rn(u[q].x, nalpha, v[q].x);  // reference vec_axpy with -alpha (cg.c:469), as cg_update_r
+            if (whole[q]) {
+                rn.y = madd_rn(u[q].y, nalpha, v[q].y);
+                *reinterpret_cast<double2 *>(upd + i) = rn;
+            } else if (any[q]) {
+                upd[i] = rn.x;
+            }
+            const double qs = wave_sum_lane63(rn.x * rn.x + rn.y * rn.y), as = wave_sum_lane63(fabs(rn.x) + fabs(rn.y));
+            if (lane == 63 && c0 + q < ncells) {
+                cellsum[c0 + q] = qs;
+                cellsum[ncells + c0 + q] = as;
+            }
+        }
+    } else {
+        const double alpha = hist[(size_t)iter * CGH_HIST + 2], beta = verdict;
+        const bool   conv = flag != 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int64_t i = (c0 + q) * XS_CELL + 2 * lane;
+            // reference vec_axpy (vec.c:88-94): x += alpha p (cg.c:467), then -- unless converged -- p = r + beta p (cg.c:489)
+            if (whole[q]) {
+                *reinterpret_cast<double2 *>(upd + i) = make_double2(madd_rn(u[q].x, alpha, v[q].x), madd_rn(u[q].y, alpha, v[q].y));
+                if (!conv) *reinterpret_cast<double2 *>(upd_p + i) = make_double2(madd_rn(w[q].x, beta, v[q].x), madd_rn(w[q].y, beta, v[q].y));
+            } else if (any[q]) {
+                upd[i] = madd_rn(u[q].x, alpha, v[q].x);
+                if (!conv) upd_p[i] = madd_rn(w[q].x, beta, v[q].x);
+            }
+        }
+    }
+}
+
 template <int KIND, bool FLAT>
 __global__ __launch_bounds__(256) void xs_fused(int64_t n, const double *__restrict__ a, const double *__restrict__ b,
                                                const double *__restrict__ c, int64_t ncells, int64_t ngroups,
@@ -1437,7 +1552,8 @@ __global__ __launch_bounds__(256) void xs_fused(int64_t n, const double *__restr
                                                xs_summary *__restrict__ groups, xs_summary *__restrict__ batches,
                                                unsigned *__restrict__ ready, int mode, double *hist, int iter, double tol, int *done,
                                                double *out, double *xfer, long long *trace, double *xu_x, const double *xu_p,
-                                               long long *wgtrace, unsigned *__restrict__ head_count)
+                                               long long *wgtrace, unsigned *__restrict__ head_count, unsigned long long *tail_box,
+                                               unsigned tail_tag)
 {
     constexpr int S0 = KIND == XS_L1 ? 1 : 0, S1 = KIND == XS_DOT ? 0 : 1, ND = S1 - S0 + 1;
     typedef xsm_shared<1> sum_shared;
@@ -1481,6 +1597,10 @@ __global__ __launch_bounds__(256) void xs_fused(int64_t n, const double *__restr
         if constexpr (FLAT) {
             xs_summarize_body<KIND, FLAT, true>(*reinterpret_cast<sum_shared *>(raw), sb, n, a, b, c, ncells, ngroups, cellsum, groupsum,
                                                  gprefix, cells, groups, nullptr, ready, batches, nbatch);
+            if constexpr (KIND != XS_L1) {
+                if (tail_box != nullptr)
+                    xs_tail<KIND>(sb, n, a, b, ncells, const_cast<double *>(cellsum), tail_box, tail_tag, xu_x, const_cast<double *>(xu_p), hist, iter);
+            }
         } else {
             // group level: summarising workgroups 0..3 share group 0 (one pass each), workgroup s >= 4 takes group s - 3
             if ((int64_t)sb >= ngroups + 3) return;
@@ -1516,6 +1636,19 @@ __global__ __launch_bounds__(256) void xs_fused(int64_t n, const double *__restr
         s_l1 = __hip_atomic_load(xfer + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     xs_finalize(KIND == XS_L1 ? 0.0 : s_dot, KIND == XS_DOT ? 0.0 : s_l1, mode, hist, iter, tol, done, out);
+    if constexpr (FLAT && KIND != XS_L1) {
+        if (tail_box != nullptr) {
+            // the verdict for the workgroups that stayed on (xs_tail): alpha behind p.Ap; beta and "converged" behind the sums of r
+            // (this thread wrote them into the history a moment ago); cg_update_xp's bookkeeping of the last finished iteration
+            if (mode == 1) {
+                xs_tail_publish(tail_box, tail_tag, hist[(size_t)iter * CGH_HIST + 2], 0u);
+            } else {
+                const bool conv = hist[(size_t)iter * CGH_HIST + 0] < tol;
+                done[2] = iter;
+                xs_tail_publish(tail_box, tail_tag, hist[(size_t)iter * CGH_HIST + 3], conv ? 1u : 0u);
+            }
+        }
+    }
 }
 
 // The sums of a vector spread over several ranks, once the last rank's part is in (cgh_xsum_finalize): one thread.
@@ -1749,9 +1882,9 @@ long long *g_xs_trace = nullptr; // device buffer of 224 words, or NULL (cgh_xsu
 template <int KIND>
 int launch_all(cgh_xsum *w, bool presummed, int64_t n, const double *a, const double *b, const double *c, int mode, double *hist, int iter,
                double tol, int *done, double *out, hipStream_t s, const double *s_in = nullptr, double *s_out = nullptr,
-               double *xu_x = nullptr, const double *xu_p = nullptr, bool *xu_taken = nullptr)
+               double *xu_x = nullptr, const double *xu_p = nullptr, int *xu_taken = nullptr)
 {
-    if (xu_taken) *xu_taken = false;
+    if (xu_taken) *xu_taken = 0;
     const unsigned ng = (unsigned)w->ngroups;
     const double *gsum = w->groupsum;
     struct consume {
@@ -1783,15 +1916,30 @@ int launch_all(cgh_xsum *w, bool presummed, int64_t n, const double *a, const do
         constexpr int ND = KIND == XS_BOTH_SAME ? 2 : 1;
         // x += alpha p rides along with the sums of r (mode 2, both sums, group level): see xs_fused
         const bool xu = KIND == XS_BOTH_SAME && !flat && mode == 2 && xu_x != nullptr && xu_p != nullptr && g_cfg.xsum_xupd;
-        if (xu_taken) *xu_taken = xu;
+        if (xu_taken) *xu_taken = xu ? 1 : 0;
+        // few cells: the vector update that consumes the verdict stays in the launch (xs_tail) -- r -= alpha Ap behind p.Ap
+        // (mode 1, xu_x = r), x += alpha p and p = r + beta p behind the sums of r (mode 2, xu_x = x, xu_p = p)
+        bool tail = flat && g_cfg.xsum_tail && w->tail != nullptr && iter > 0 && hist != nullptr && done != nullptr && xu_x != nullptr &&
+                    ((KIND == XS_DOT && mode == 1) || (KIND == XS_BOTH_SAME && mode == 2 && xu_p != nullptr));
+        if (tail) {
+            // (not under stream capture: a replayed launch carries the same tag as the replay before it, whose verdict is
+            // still in the box -- right only as long as nothing about the solve changed in between)
+            hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+            (void)hipStreamIsCapturing(s, &cap);
+            tail = cap == hipStreamCaptureStatusNone;
+        }
+        if (tail && xu_taken) *xu_taken = 2;
+        const unsigned tag = tail ? 0x80000000u | (++w->tail_seq & 0x7fffffffu) : 0u;
         if (flat)
             hipLaunchKernelGGL((xs_fused<KIND, true>), dim3(4 * ng + ND), dim3(256), 0, s, n, a, b, c, w->ncells, w->ngroups,
                                (const double *)w->cellsum, gsum, prefix, w->cells, w->groups, w->batches, w->ready, mode, hist, iter, tol, done,
-                               out, w->xfer, g_xs_trace, (double *)nullptr, (const double *)nullptr, g_xs_wgtrace, w->head);
+                               out, w->xfer, g_xs_trace, tail ? xu_x : nullptr, tail ? xu_p : nullptr, g_xs_wgtrace, w->head,
+                               tail ? w->tail : nullptr, tag);
         else
             hipLaunchKernelGGL((xs_fused<KIND, false>), dim3(xu ? 5 * ((ng + 3 + 3) / 4) + ND : ng + 3 + ND), dim3(256), 0, s, n, a, b, c, w->ncells,
                                w->ngroups, (const double *)w->cellsum, gsum, prefix, w->cells, w->groups, w->batches, w->ready, mode, hist, iter,
-                               tol, done, out, w->xfer, g_xs_trace, xu ? xu_x : nullptr, xu ? xu_p : nullptr, g_xs_wgtrace, w->head);
+                               tol, done, out, w->xfer, g_xs_trace, xu ? xu_x : nullptr, xu ? xu_p : nullptr, g_xs_wgtrace, w->head,
+                               (unsigned long long *)nullptr, 0u);
         CGH_HIP(hipGetLastError());
         return CGH_OK;
     }
@@ -1837,7 +1985,12 @@ cgh_xsum *cgh_xsum_create(int64_t n)
         w->ready = nullptr;
     }
     w->batches = (xs_summary *)cgh_alloc(sizeof(xs_summary) * nready);
-    if (!w->cellsum || !w->groupsum || !w->gprefix || !w->cells || !w->groups || !w->xfer || !w->ready || !w->batches) {
+    w->tail = (unsigned long long *)cgh_alloc(sizeof(unsigned long long) * 8);
+    if (w->tail && hipMemset(w->tail, 0, sizeof(unsigned long long) * 8) != hipSuccess) {
+        cgh_free(w->tail);
+        w->tail = nullptr;
+    }
+    if (!w->cellsum || !w->groupsum || !w->gprefix || !w->cells || !w->groups || !w->xfer || !w->ready || !w->batches || !w->tail) {
         cgh_xsum_free(w);
         return nullptr;
     }
@@ -1856,7 +2009,7 @@ size_t cgh_xsum_device_bytes(int64_t n)
     const size_t nready = 2 * ((ngroups + 63) / 64 > 32 ? (ngroups + 63) / 64 : 32);
     return xs_up256(sizeof(double) * 2 * ncells) + 2 * xs_up256(sizeof(double) * 2 * ngroups) + xs_up256(sizeof(xs_summary) * 2 * ncells) +
            xs_up256(sizeof(xs_summary) * 2 * ngroups) + xs_up256(sizeof(double) * 4) + xs_up256(sizeof(unsigned) * (nready + 8)) +
-           xs_up256(sizeof(xs_summary) * nready);
+           xs_up256(sizeof(xs_summary) * nready) + xs_up256(sizeof(unsigned long long) * 8);
 }
 cgh_xsum *cgh_xsum_place(void *obj, size_t obj_bytes, int64_t n, void *dev, size_t dev_bytes, hipStream_t s)
 {
@@ -1879,7 +2032,9 @@ cgh_xsum *cgh_xsum_place(void *obj, size_t obj_bytes, int64_t n, void *dev, size
     w->ready = (unsigned *)take(sizeof(unsigned) * (nready + 8));
     w->head = w->ready + nready;
     w->batches = (xs_summary *)take(sizeof(xs_summary) * nready);
-    if (hipMemsetAsync(w->xfer, 0, sizeof(double) * 4, s) != hipSuccess || hipMemsetAsync(w->ready, 0, sizeof(unsigned) * (nready + 8), s) != hipSuccess)
+    w->tail = (unsigned long long *)take(sizeof(unsigned long long) * 8);
+    if (hipMemsetAsync(w->xfer, 0, sizeof(double) * 4, s) != hipSuccess || hipMemsetAsync(w->ready, 0, sizeof(unsigned) * (nready + 8), s) != hipSuccess ||
+        hipMemsetAsync(w->tail, 0, sizeof(unsigned long long) * 8, s) != hipSuccess)
         return nullptr;
     return w;
 }
@@ -1895,6 +2050,7 @@ void cgh_xsum_free(cgh_xsum *w)
     cgh_free(w->xfer);
     cgh_free(w->ready);
     cgh_free(w->batches);
+    cgh_free(w->tail);
     delete w;
 }
 
@@ -1995,9 +2151,9 @@ int cgh_xsum_finalize(const double *sums, int mode, double *hist, int iter, doub
 
 int cgh_xsum_launch(cgh_xsum *w, int64_t n, const double *a, const double *b, const double *c, int mode, double *hist,
                     int iter, double tol, int *done, double *out, hipStream_t s, bool presummed, double *xu_x, const double *xu_p,
-                    bool *xu_taken)
+                    int *xu_taken)
 {
-    if (xu_taken) *xu_taken = false;
+    if (xu_taken) *xu_taken = 0;
     if (!w || n != w->n) {
         cgh_set_error("cgh_xsum_launch: workspace was created for another length");
         return CGH_EINVAL;
@@ -2008,7 +2164,7 @@ int cgh_xsum_launch(cgh_xsum *w, int64_t n, const double *a, const double *b, co
         cgh_set_error("cgh_xsum_launch: vectors must be 16-byte aligned");
         return CGH_EINVAL;
     }
-    if (a && b && !c) return launch_all<XS_DOT>(w, presummed, n, a, b, c, mode, hist, iter, tol, done, out, s);
+    if (a && b && !c) return launch_all<XS_DOT>(w, presummed, n, a, b, c, mode, hist, iter, tol, done, out, s, nullptr, nullptr, xu_x, xu_p, xu_taken);
     if (!a && !b && c) return launch_all<XS_L1>(w, presummed, n, a, b, c, mode, hist, iter, tol, done, out, s);
     if (a && a == b && a == c)
         return launch_all<XS_BOTH_SAME>(w, presummed, n, a, b, c, mode, hist, iter, tol, done, out, s, nullptr, nullptr, xu_x, xu_p, xu_taken);

@@ -268,3 +268,27 @@ def test_jacobi_graph_replay_matches_eager(cga, monkeypatch):
     rep2, hist2 = cga.cg_solve(A, b, x2, max_iter=300, tol=1e-8, strict=0, precond=1, check_every=16)
     assert rep.ret > 0 and rep2.ret == rep.ret and same_bits_nan(hist2, hist)
     assert np.array_equal(bits(x2.to_host()), bits(x.to_host()))
+
+
+@pytest.mark.parametrize("shape", [(16, 16, 16), (21, 15, 13), (32, 32, 31), (63, 65, 32), (64, 64, 64)])
+def test_strict_cg_same_bits_with_the_vector_updates_in_the_sums_launches(cga, monkeypatch, shape):
+    """Few cells (4096 .. 262 144 rows; odd lengths too): the launches of the sums keep their workgroups for the vector update
+    behind the verdict (xs_tail: r -= alpha Ap behind p.Ap; x += alpha p and p = r + beta p behind the sums of r), so a strict
+    iteration is three launches instead of five.  Against CGH_XSUM_TAIL=0 (cg_update_r / cg_update_xp as launches of their
+    own): history, return value, x bit-identical -- converging solves (the converging iteration updates x and leaves p alone;
+    iterations queued behind it do nothing) and a fixed number of iterations."""
+    n = shape[0] * shape[1] * shape[2]
+    for kw in (dict(max_iter=300, tol=1e-4, check_every=16), dict(fixed_iters=25)):
+        got = []
+        for tail in ("1", "0"):
+            setknob(monkeypatch, "CGH_XSUM_TAIL", tail)
+            b = cga.DeviceVector(n); x = cga.DeviceVector(n)
+            A = cga.Matrix.poisson(*shape, 7, 0x5EED0001, cga.LAYOUT_ELL, b)
+            rep, hist = cga.cg_solve(A, b, x, strict=1, **kw)
+            got.append((rep.ret, hist.copy(), x.to_host()))
+        assert got[0][0] == got[1][0], (shape, kw)
+        assert same_bits_nan(got[0][1], got[1][1]), (shape, kw)
+        assert np.array_equal(bits(got[0][2]), bits(got[1][2])), (shape, kw)
+        if "tol" in kw:
+            assert 1 < got[0][0] < 300
+    setknob(monkeypatch, "CGH_XSUM_TAIL", "1")
