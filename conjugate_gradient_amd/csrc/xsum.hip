@@ -1292,13 +1292,14 @@ __device__ double xr_sum(xr_shared &S, int slot, int64_t n, const double *__rest
     double         s = 0.0;
     int            cur = 0;
     int            head = 0;  // cells at the front of the sum that the walk has already added element by element
-    if constexpr (FLAT) {
-        // Few cells: the launch is short, the walk is its critical path -- and until the first batch's summaries are in
-        // memory (6.6 us after the start at 32 768 elements) the walk has nothing to do, while the front of a sum is where it
-        // is slowest (the running sum doubles every few elements: the first cells are the ones that end up being added
-        // element by element anyway).  So the walking wave starts on them at once, one cell per 0.7 us with the next
-        // cell's elements in flight, and hands over to the summaries as soon as the first batch is ready; the summaries of
-        // the cells it got through are then simply not used (xs_batch starts behind them).
+    {
+        // Until the first batch's summaries are in memory (6.6 us after the start at 32 768 elements, 21 us at 2.1M) the
+        // walk has nothing to do, while the front of a sum is where it is slowest (the running sum doubles every few
+        // elements: the first cells are the ones that end up being added element by element anyway) -- and up to a few
+        // million elements the walk is the launch's critical path.  So the walking wave starts on the first group's cells
+        // at once, one cell per 0.7 us with the next cell's elements in flight, and hands over to the summaries as soon
+        // as the first batch is ready; the summaries of the cells it got through are then simply not used (xs_batch starts
+        // behind them).
         const int ccnt0 = (int)(ncells < XS_GROUP ? ncells : XS_GROUP);
         double    e0, e1;
         xs_cell_terms<KIND>(slot, n, a, b, c, 0, e0, e1);
@@ -1370,6 +1371,7 @@ __device__ double xr_sum(xr_shared &S, int slot, int64_t n, const double *__rest
                 const int     gcnt = (int)(ngroups - (int64_t)bb * 64 < 64 ? ngroups - (int64_t)bb * 64 : 64);
                 xs_summary    Gq = xs_identity();
                 if (lane < gcnt) Gq = xs_load_agent(groups + (int64_t)bb * 64 + lane);
+                if (bb == 0 && lane == 0 && head > 0) Gq = xs_regular(0, 0, 0, 0, 0, true);  // the walk is inside group 0 already
                 const int64_t Ginc = xs_scan(Gq, gcnt);
                 int           gstart = 0;
                 while (gstart < gcnt) {
@@ -1380,7 +1382,7 @@ __device__ double xr_sum(xr_shared &S, int slot, int64_t n, const double *__rest
                     xs_summary    Cq = xs_identity();
                     if (lane < ccnt) Cq = xs_load_agent(cells + c0 + lane);
                     const int64_t Cinc = xs_scan(Cq, ccnt);
-                    int           cstart = 0;
+                    int           cstart = it == 0 ? head : 0;  // (the first `head` cells of the sum are in s already)
                     while (cstart < ccnt) {
                         const int cf = xs_batch(Cq, Cinc, cstart, ccnt, s);
                         if (cf >= ccnt) break;
