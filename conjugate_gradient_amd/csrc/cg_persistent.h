@@ -16,9 +16,10 @@
 // So an iteration has two dependent cross-workgroup round trips.  No grid barrier, no flag, no fence: a word is valid
 // exactly when its tag matches.  One slot per buffer suffices: a workgroup can only overwrite a word after a
 // reduction that needed every other workgroup to be past its last read of that word (pa: the r.r reduction lies
-// between; pb and the image of r: the next p.Ap reduction does).  Every wait gives up after 2 s (error word, NaN), after which nobody waits
-// again, so the grid always drains.  All workgroups derive the same scalars from the same partials, reach the same
-// verdict and leave at the same iteration.
+// between; pb and the image of r: the next p.Ap reduction does).  Every wait gives up after 2 s (error word, NaN),
+// after which nobody waits again, so the grid always drains.  All workgroups derive the same scalars from the same
+// partials, reach the same verdict and leave at the same iteration.  (Tags hold 13 bits of the iteration number: every
+// word is rewritten every iteration, so a word never carries a tag 8192 iterations old.)
 //
 // Bits: identical to the three-launch path (same per-row arithmetic, same per-tile partials -- cg.hip gives every tile
 // its own workgroup at these sizes --, same order of the partials' sum).
