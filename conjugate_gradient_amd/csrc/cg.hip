@@ -39,9 +39,13 @@ struct scratch_buf {
     scratch_buf &operator=(const scratch_buf &) = delete;
 };
 
+// Grid of the vector kernels: four workgroups per CU, each walking its chunks of 512 rows grid-stride.  (Eight per CU --
+// every workgroup slot of the chip taken at once -- was the choice of rounds 1 and 2; measured in round 3, us per
+// iteration of the throughput loop, 8 -> 4 per CU: 256^3 408 -> 400, 4.2M rows 104.7 -> 102, 1M rows 35.0 -> 31.8; three per CU
+// the same, grids that are no multiple of the CU count (640, 896) lose 3 %.)
 int vec_grid(int64_t n)
 {
-    return cgh_stream_grid((n + 2 * CGH_BLOCK - 1) / (2 * CGH_BLOCK), 8);
+    return cgh_stream_grid((n + 2 * CGH_BLOCK - 1) / (2 * CGH_BLOCK), 4);
 }
 
 // Vectors of at least this many elements take the order-exact PARALLEL sums of xsum.hip in strict mode; shorter ones
