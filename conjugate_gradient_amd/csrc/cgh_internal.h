@@ -117,6 +117,7 @@ struct cgh_config {
     int    ell_generic = 0;     // CGH_ELL_GENERIC: runtime-K ELL kernel for every width (tests)
     int    ell_dict = -1;       // CGH_ELL_DICT: 0 no dictionary-coded columns, 1 / 2 force the byte / packed layout, -1 automatic
     int    ell_variant = -1;    // CGH_ELL_VARIANT: cache-hint variant of the ELL SpMV, -1 = by working-set size
+    int    ell_wgs = 0;         // CGH_ELL_WGS: workgroups per CU of the ELL SpMV's tile walk (0 = by kernel: 5 narrow byte-coded rows, else 8)
     double llc_mb = 224.0;      // CGH_LLC_MB: working sets below this many MiB run without streaming hints
     int    csr_window = 1024;   // CGH_CSR_WINDOW: entries per row block of the CSR stream kernel (512 | 1024 | 2048)
     int    csr_exact = 0;       // CGH_CSR_EXACT: every CSR row summed strictly left to right

@@ -65,6 +65,7 @@ static void read_env_knobs()
     g_cfg.vec_variant = env_int("CGH_VEC_VARIANT", g_cfg.vec_variant);
     g_cfg.graph = env_int("CGH_GRAPH", g_cfg.graph);
     g_cfg.persistent = env_int("CGH_PERSISTENT", g_cfg.persistent);
+    g_cfg.ell_wgs = env_int("CGH_ELL_WGS", g_cfg.ell_wgs);
     g_cfg.xsum_tail = env_int("CGH_XSUM_TAIL", g_cfg.xsum_tail);
     if (getenv("CGH_GRAPH_MAX_ROWS")) g_cfg.graph_max_rows = atoll(getenv("CGH_GRAPH_MAX_ROWS"));
     g_cfg.csrb_rpw = env_int("CGH_CSRB_RPW", g_cfg.csrb_rpw);

@@ -475,17 +475,28 @@ bool cgh_fits_llc(const cgh_matrix *m, double times)
     return (double)m->stored * per_entry + (double)m->n * 8.0 * 5.0 <= limit * times;
 }
 
-static int ell_grid_rows(int64_t rows)
+// Workgroups per CU of the tile walk.  Narrow rows with byte-coded columns (the 7-point kernel: 64 VGPRs, so eight
+// workgroups per CU would be resident) run fastest with FIVE per CU -- measured in round 3 at 256^3, us per CG iteration:
+// 2048 workgroups 400.3, 1536 388.5, 1280 373.4, 1024 378.9, 768 396.6, 512 460 (grids that are no multiple of the CU count
+// lose: 1152 393, 1408 411); 4.2M rows 101.9 -> 98.4, 8.4M 194.8 -> 189.8.  Wide rows (27-point, 220 VGPRs: two workgroups per
+// CU resident whatever the grid) and int32 columns keep eight (0.845 vs 0.854 ms; 445.5 vs 450.1 us).  CGH_ELL_WGS overrides.
+static int ell_wgs_per_cu(const cgh_matrix *m)
+{
+    if (g_cfg.ell_wgs > 0) return g_cfg.ell_wgs;
+    return m != nullptr && m->dict_state == 1 && m->dict_mode == 1 && m->K <= 8 ? 5 : 8;
+}
+
+static int ell_grid_rows(int64_t rows, int per_cu)
 {
     // tiles of 512 rows (256 threads x 2 rows); grid a multiple of 8 so tile%8 -> XCD group is stable
     const int64_t tiles = (rows + 2 * CGH_BLOCK - 1) / (2 * CGH_BLOCK);
     if (tiles <= CGH_ELL_SMALL_TILES) return (int)(tiles < 1 ? 1 : tiles);  // small: one workgroup per tile, in order
-    int           g = cgh_stream_grid(tiles, 8);
+    int           g = cgh_stream_grid(tiles, per_cu);
     if (g >= 8) g -= g % 8;
     return g;
 }
 
-int cgh_ell_grid(const cgh_matrix *m) { return ell_grid_rows(m->n); }
+int cgh_ell_grid(const cgh_matrix *m) { return ell_grid_rows(m->n, ell_wgs_per_cu(m)); }
 
 // y[rb:re) = (A x)[rb:re).  The slot stride is m->n; x may be longer than n (multi-GPU: halo entries follow the owned ones).
 int cgh_launch_spmv_ell_range(const cgh_matrix *m, const double *x, double *y, double *dot_partials, int *grid_out,
@@ -510,9 +521,22 @@ int cgh_launch_spmv_ell_range2(const cgh_matrix *m, const double *x, double *y, 
     if (re < rb) re = rb;
     if (re2 < rb2) re2 = rb2;
     const int64_t rows = (re - rb) + (re2 - rb2);
-    const int grid = ell_grid_rows(rows);
-    if (grid_out) *grid_out = rows > 0 ? grid : 0;
+    if (grid_out) *grid_out = 0;
     if (rows <= 0) return CGH_OK;
+    const bool vector_path = ell_vector_path(m, x, y) && rb % 2 == 0 && re % 2 == 0 && rb2 % 2 == 0 && re2 % 2 == 0;
+    // the column dictionary is decided before the grid is: the grid depends on which kernel runs
+    if (vector_path && __atomic_load_n(&m->dict_state, __ATOMIC_ACQUIRE) == 0 && !(opts && opts->no_alloc)) {
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        (void)hipStreamIsCapturing(s, &cap);
+        if (cap == hipStreamCaptureStatusNone) {
+            // the one place a launch path changes a (logically const) matrix: once, under a lock; the state word is
+            // published last, so a thread that does not take the lock sees either "not built" or a complete dictionary
+            std::lock_guard<std::mutex> guard(g_dict_mutex);
+            if (m->dict_state == 0) ell_dict_try_build(m, s);
+        }
+    }
+    const int grid = ell_grid_rows(rows, vector_path ? ell_wgs_per_cu(m) : 8);
+    if (grid_out) *grid_out = grid;
     if (!(ell_vector_path(m, x, y) && rb % 2 == 0 && re % 2 == 0 && rb2 % 2 == 0 && re2 % 2 == 0) && re2 > rb2) {
         // scalar path: one launch per range
         int g1 = 0, g2 = 0;
@@ -523,16 +547,6 @@ int cgh_launch_spmv_ell_range2(const cgh_matrix *m, const double *x, double *y, 
         return rc;
     }
     if (ell_vector_path(m, x, y) && rb % 2 == 0 && re % 2 == 0 && rb2 % 2 == 0 && re2 % 2 == 0) {
-        if (__atomic_load_n(&m->dict_state, __ATOMIC_ACQUIRE) == 0 && !(opts && opts->no_alloc)) {
-            hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-            (void)hipStreamIsCapturing(s, &cap);
-            if (cap == hipStreamCaptureStatusNone) {
-                // the one place a launch path changes a (logically const) matrix: once, under a lock; the state word is
-                // published last, so a thread that does not take the lock sees either "not built" or a complete dictionary
-                std::lock_guard<std::mutex> guard(g_dict_mutex);
-                if (m->dict_state == 0) ell_dict_try_build(m, s);
-            }
-        }
         // strict mode's per-cell sums of x.y instead of per-workgroup partials
         if (cell_sums != nullptr && dot_partials == nullptr && rb == 0 && re == m->n && re2 <= rb2 && m->n % 128 == 0) {
             if (m->dict_state == 1 && m->dict_mode == 2)
@@ -621,14 +635,15 @@ int cgh_launch_spmv_ell_halo(const cgh_matrix *m, const double *x, double *y, do
     if (re < rb) re = rb;
     if (re2 < rb2) re2 = rb2;
     const int64_t rows = (re - rb) + (re2 - rb2);
-    const int grid = ell_grid_rows(rows);
-    if (grid_out) *grid_out = rows > 0 ? grid : 0;
+    if (grid_out) *grid_out = 0;
     if (!cgh_spmv_ell_halo_capable(m, x, y, rb, re, rb2, re2) || !dot_partials) return CGH_EINVAL;
     if (rows <= 0) return CGH_OK;
     if (__atomic_load_n(&m->dict_state, __ATOMIC_ACQUIRE) == 0) {
         std::lock_guard<std::mutex> guard(g_dict_mutex);
         if (m->dict_state == 0) ell_dict_try_build(m, s);
     }
+    const int grid = ell_grid_rows(rows, ell_wgs_per_cu(m));
+    if (grid_out) *grid_out = grid;
 #define CGH_ELL_HALO_LAUNCH(V)                                                                                                 \
     if (m->dict_state == 1 && m->dict_mode == 2)                                                                               \
         launch_r2<1, V, 2, 1>(m->K, grid, s, m->n, m->diag, m->vals, m->cols8, m->off_tab, x, y, dot_partials, done, rb, re, rb2, re2, \
