@@ -66,6 +66,7 @@ def lib():
     L.cgh_config_sell_sigma.argtypes = [C.c_int]
     L.cgh_config_persistent.argtypes = [C.c_int]
     L.cgh_persistent_set_trace.argtypes = [C.c_void_p]
+    L.cgh_time_read_variant.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_double)]
     L.cgh_solver_is_resident.argtypes = [C.c_void_p]
     L.cgh_persistent_launches.restype = C.c_longlong
     L.cgh_csrb_plan_host.argtypes = [i64, ip, C.c_int, ip, ip]

@@ -66,6 +66,7 @@ struct timing_events {
     }
 };
 
+constexpr int CGH_READ_WGS_PER_CU = 3;  // of the read ceiling: 2-3 per CU 7.13-7.16 TB/s, 5 or 7 7.0, 6 6.55, but 4 5.73 and 8 (rounds 1-2) 5.90 -- power-of-two strides between the workgroups alias in the memory channels (profiles/r03_read_sweep.txt)
 // read-only stream: 4 independent 16-byte non-temporal loads in flight per lane, one word per workgroup written
 __global__ __launch_bounds__(256) void read16(const u4_t *__restrict__ src, unsigned *__restrict__ sink, size_t count)
 {
@@ -317,12 +318,19 @@ int cgh_time_copy(void *d_dst, const void *d_src, size_t bytes, int reps, double
 }
 
 // Read-only ceiling: `bytes` streamed from d_src once per repetition (16-byte non-temporal loads), nothing written.
+// wgs_per_cu: workgroups per CU of the grid-stride walk (1..8; tools/quick_copy.py sweeps it).
+int cgh_time_read_variant(const void *d_src, void *d_sink_8k, size_t bytes, int reps, int wgs_per_cu, double *ms_avg);
 int cgh_time_read(const void *d_src, void *d_sink_8k, size_t bytes, int reps, double *ms_avg)
 {
+    return cgh_time_read_variant(d_src, d_sink_8k, bytes, reps, CGH_READ_WGS_PER_CU, ms_avg);
+}
+
+int cgh_time_read_variant(const void *d_src, void *d_sink_8k, size_t bytes, int reps, int wgs_per_cu, double *ms_avg)
+{
     CGH_REQUIRE_READY(CGH_ENODEV);
-    if (bytes % 16 || reps < 1 || !d_src || !d_sink_8k) return CGH_EINVAL;
+    if (bytes % 16 || reps < 1 || !d_src || !d_sink_8k || wgs_per_cu < 1 || wgs_per_cu > 8) return CGH_EINVAL;
     hipStream_t s = g_cgh.stream;
-    const int   grid = g_cgh.num_cu * 8;  // <= 2048 workgroups: the sink holds 8 KiB
+    const int   grid = g_cgh.num_cu * wgs_per_cu;  // <= 2048 workgroups: the sink holds 8 KiB
     if (grid > 2048) return CGH_EINVAL;
     timing_events ev;
     CGH_HIP(hipEventCreate(&ev.a));

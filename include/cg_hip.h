@@ -344,6 +344,7 @@ int cgh_time_copy_variant(void *d_dst, const void *d_src, size_t bytes, int reps
 void cgh_xsum_set_prof(void *dev_16_words);
 /* read-only stream of `bytes` from d_src (d_sink_8k: 8 KiB of device scratch): the ceiling for read-dominated kernels */
 int cgh_time_read(const void *d_src, void *d_sink_8k, size_t bytes, int reps, double *ms_avg);
+int     cgh_time_read_variant(const void *d_src, void *d_sink_8k, size_t bytes, int reps, int wgs_per_cu, double *ms_avg);  /* the same with 1..8 workgroups per CU */
 /* `count` 8-byte words from d_src8 plus `count` 4-byte words from d_src4, one of each per lane and step (how the CSR-family
  * kernels stream a matrix): a stream of known size that calibrates the FETCH_SIZE counter for those access widths */
 int cgh_time_read_8_4(const void *d_src8, const void *d_src4, void *d_sink_8k, size_t count, int reps, double *ms_avg);
