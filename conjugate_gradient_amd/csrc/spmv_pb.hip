@@ -158,9 +158,23 @@ __global__ __launch_bounds__(SPAN / 16) void pb_expand(int B, int split, const i
     if (done != nullptr && *done != 0) return;
     const int s = B - 1 - (int)(blockIdx.x / split), part = (int)(blockIdx.x % split);  // later blocks (denser rows) first
     const int r0 = bnd[s], cnt = bnd[s + 1] - r0;
-    for (int i = threadIdx.x; i < cnt; i += T) xs[i] = x[r0 + i];
-    for (int i = threadIdx.x; i <= B; i += T) pre_s[i] = pre[(size_t)s * (B + 1) + i];
-    for (int i = threadIdx.x; i < B; i += T) st_s[i] = seg0[(size_t)s * B + i];
+    {
+        // cnt <= SPAN = 16 T: the block's x in one round trip (a loop of load -> LDS store pays the memory latency 16 times
+        // over while the CU's one workgroup does nothing else), the two tables behind it
+        double t[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int i = threadIdx.x + q * T;
+            t[q] = i < cnt ? x[r0 + i] : 0.0;
+        }
+        for (int i = threadIdx.x; i <= B; i += T) pre_s[i] = pre[(size_t)s * (B + 1) + i];
+        for (int i = threadIdx.x; i < B; i += T) st_s[i] = seg0[(size_t)s * B + i];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int i = threadIdx.x + q * T;
+            if (i < cnt) xs[i] = t[q];
+        }
+    }
     __syncthreads();
     const int tot = pre_s[B];  // a multiple of PAD
     const int lane = threadIdx.x & 63;
@@ -180,35 +194,49 @@ __global__ __launch_bounds__(SPAN / 16) void pb_expand(int B, int split, const i
         }
         b = lo;
     }
-    for (; f < fend; f += 128 * UN) {
+    // A piece = UN chunks of 128 entries.  The loads of the next piece are issued before the products of this one are formed
+    // and stored: two pieces' loads are in flight per lane (the positions depend on the tables in LDS only).
+    struct piece {
         d2_t     v[UN];
         unsigned c[UN], k[UN];
         bool     act[UN];
-        int      bu = b;
+    };
+    auto fetch = [&](piece &pc, int at) {
+        int bu = b;
 #pragma unroll
         for (int q = 0; q < UN; ++q) {
-            const int fu = f + q * 128 + 2 * lane;  // even, segments are multiples of 16: the pair lies in one segment
-            act[q] = fu < fend;
-            v[q] = d2_t{0.0, 0.0};
-            c[q] = 0;
-            k[q] = 0;
-            if (act[q]) {
+            const int fu = at + q * 128 + 2 * lane;  // even, segments are multiples of 16: the pair lies in one segment
+            pc.act[q] = fu < fend;
+            pc.v[q] = d2_t{0.0, 0.0};
+            pc.c[q] = 0;
+            pc.k[q] = 0;
+            if (pc.act[q]) {
                 while (fu >= pre_s[bu + 1]) ++bu;  // fu < tot = pre_s[B]: stops at bu <= B - 1
-                k[q] = st_s[bu] + (unsigned)(fu - pre_s[bu]);
-                v[q] = __builtin_nontemporal_load((const d2_t *)(vals + k[q]));
-                c[q] = __builtin_nontemporal_load((const unsigned *)(lcol + k[q]));
+                pc.k[q] = st_s[bu] + (unsigned)(fu - pre_s[bu]);
+                pc.v[q] = __builtin_nontemporal_load((const d2_t *)(vals + pc.k[q]));
+                pc.c[q] = __builtin_nontemporal_load((const unsigned *)(lcol + pc.k[q]));
             }
         }
+        b = __builtin_amdgcn_readfirstlane(bu);  // lane 0's cursor: its last position is below the next piece's first
+    };
+    auto emit = [&](const piece &pc) {
 #pragma unroll
         for (int q = 0; q < UN; ++q)
-            if (act[q]) {
+            if (pc.act[q]) {
                 d2_t pr;
-                pr.x = mul_rn(v[q].x, xs[c[q] & 0xffffu]);
-                pr.y = mul_rn(v[q].y, xs[c[q] >> 16]);
+                pr.x = mul_rn(pc.v[q].x, xs[pc.c[q] & 0xffffu]);
+                pr.y = mul_rn(pc.v[q].y, xs[pc.c[q] >> 16]);
                 // streamed: plain stores finish this kernel 7 % sooner and make the next one 25 % slower
-                __builtin_nontemporal_store(pr, (d2_t *)(prod + k[q]));
+                __builtin_nontemporal_store(pr, (d2_t *)(prod + pc.k[q]));
             }
-        b = __builtin_amdgcn_readfirstlane(bu);  // lane 0's cursor: its last position is below the next f
+    };
+    piece pa, pb;
+    fetch(pa, f);
+    for (; f < fend; f += 2 * 128 * UN) {
+        fetch(pb, f + 128 * UN);  // (past fend: nothing is active, the cursor stays)
+        emit(pa);
+        fetch(pa, f + 2 * 128 * UN);
+        emit(pb);
     }
 }
 
@@ -240,41 +268,72 @@ __global__ __launch_bounds__(SPAN / 16) void pb_accumulate(int B, const int *__r
     // a piece = UN x 128 consecutive entries of ONE wave (ORDERED) / UN x 2 T entries of the workgroup, lane pairs interleaved
     constexpr int UN = ORDERED ? 8 : 4;
     const int64_t pieces = ORDERED ? (k1 - k0 + UN * 128 - 1) / (UN * 128) : (k1 - k0 + 2 * UN * T - 1) / (2 * UN * T);
-    for (int64_t pc = ORDERED ? wave : 0; pc < pieces; pc += ORDERED ? NW : 1) {
-        d2_t     p[UN];
-        unsigned r[UN];
+    if constexpr (ORDERED) {
+        for (int64_t pc = wave; pc < pieces; pc += NW) {
+            d2_t     p[UN];
+            unsigned r[UN];
 #pragma unroll
-        for (int q = 0; q < UN; ++q) {
-            const int64_t kq = ORDERED ? k0 + pc * (UN * 128) + q * 128 + 2 * lane : k0 + pc * 2 * UN * T + q * 2 * T + 2 * threadIdx.x;
-            p[q] = d2_t{0.0, 0.0};
-            r[q] = 0xffffffffu;
-            if (kq < k1) {
-                p[q] = __builtin_nontemporal_load((const d2_t *)(prod + kq));
-                r[q] = __builtin_nontemporal_load((const unsigned *)(lrow + kq));
+            for (int q = 0; q < UN; ++q) {
+                const int64_t kq = k0 + pc * (UN * 128) + q * 128 + 2 * lane;
+                p[q] = d2_t{0.0, 0.0};
+                r[q] = 0xffffffffu;
+                if (kq < k1) {
+                    p[q] = __builtin_nontemporal_load((const d2_t *)(prod + kq));
+                    r[q] = __builtin_nontemporal_load((const unsigned *)(lrow + kq));
+                }
             }
-        }
-        if constexpr (ORDERED) {
             // acquire / release (an lgkmcnt wait each on gfx950): the adds below stay behind the ticket they wait for and
             // ahead of the one they hand on, whatever the compiler would like to do with relaxed atomics to other addresses
             while (__hip_atomic_load(&ticket, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != (int)pc) {
             }
-        }
 #pragma unroll
-        for (int q = 0; q < UN; ++q) {
-            if ((r[q] & 0xffffu) != 0xffffu) unsafeAtomicAdd(&acc[r[q] & 0xffffu], p[q].x);
-            if ((r[q] >> 16) != 0xffffu) unsafeAtomicAdd(&acc[r[q] >> 16], p[q].y);
-        }
-        if constexpr (ORDERED) {
+            for (int q = 0; q < UN; ++q) {
+                if ((r[q] & 0xffffu) != 0xffffu) unsafeAtomicAdd(&acc[r[q] & 0xffffu], p[q].x);
+                if ((r[q] >> 16) != 0xffffu) unsafeAtomicAdd(&acc[r[q] >> 16], p[q].y);
+            }
             if (lane == 0) __hip_atomic_store(&ticket, (int)pc + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    } else {
+        for (int64_t pc = 0; pc < pieces; ++pc) {
+            d2_t     p[UN];
+            unsigned r[UN];
+#pragma unroll
+            for (int q = 0; q < UN; ++q) {
+                const int64_t kq = k0 + pc * 2 * UN * T + q * 2 * T + 2 * threadIdx.x;
+                p[q] = d2_t{0.0, 0.0};
+                r[q] = 0xffffffffu;
+                if (kq < k1) {
+                    p[q] = __builtin_nontemporal_load((const d2_t *)(prod + kq));
+                    r[q] = __builtin_nontemporal_load((const unsigned *)(lrow + kq));
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < UN; ++q) {
+                if ((r[q] & 0xffffu) != 0xffffu) unsafeAtomicAdd(&acc[r[q] & 0xffffu], p[q].x);
+                if ((r[q] >> 16) != 0xffffu) unsafeAtomicAdd(&acc[r[q] >> 16], p[q].y);
+            }
         }
     }
     __syncthreads();
     double local = 0.0;
-    for (int i = threadIdx.x; i < cnt; i += T) {  // diag and x are read once, here
-        const double xr = x[r0 + i];
-        const double yv = add_rn(0.0, mul_rn(diag[r0 + i], xr)) + acc[i];
-        __builtin_nontemporal_store(yv, y + r0 + i);
-        if (DOT) local += xr * yv;
+    // diag and x are read once, here; cnt <= SPAN = 16 T: four rows per lane and round trip
+    for (int i0 = threadIdx.x; i0 < cnt; i0 += 4 * T) {
+        double dg[4], xr[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = i0 + q * T;
+            dg[q] = i < cnt ? diag[r0 + i] : 0.0;
+            xr[q] = i < cnt ? x[r0 + i] : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = i0 + q * T;
+            if (i < cnt) {
+                const double yv = add_rn(0.0, mul_rn(dg[q], xr[q])) + acc[i];
+                __builtin_nontemporal_store(yv, y + r0 + i);
+                if (DOT) local += xr[q] * yv;
+            }
+        }
     }
     if constexpr (DOT) {
         local = wave_sum(local);
