@@ -142,7 +142,7 @@ __global__ __launch_bounds__(256) void pb_tables(int B, const int64_t *__restric
 // pb_expand.  The work of column block s is the concatenation of its B segments (flat positions 0..tot); it is dealt in
 // contiguous pieces of 128-entry chunks to the workgroup's waves (and to `split` workgroups per block), so a wave walks
 // a few neighbouring segments front to back.  A lane finds its segment by stepping a cursor through the LDS table from
-// the wave's own (uniform) cursor; UN chunks are in flight per lane.
+// the wave's own (uniform) cursor; two pieces of UN chunks are in flight per lane.
 typedef double d2_t __attribute__((ext_vector_type(2)));
 
 template <int SPAN, int UN = 4>
