@@ -90,15 +90,16 @@ struct cgh_matrix {
     // perm[p] = row stored at position p (slice p/64, lane p%64), -1 beyond the last row
     int     *perm = nullptr;
     int      sigma = 0;
-    // PB (two-phase SpMV, spmv_pb.hip): rows = columns cut into pb_blocks blocks (pb_bnd, at most pb_span rows each); vals[] sorted
-    // by (row block, column block) with 2-byte local columns / rows; pb_prod is the launch's product stream (workspace of the
-    // matrix: launches on one matrix must not overlap)
+    // PB (two-phase SpMV, spmv_pb.hip): rows = columns cut into pb_blocks blocks (pb_bnd, at most pb_span rows each); vals[] and
+    // the 2-byte local columns sorted by (column block, row block), the 2-byte local rows and the launch's product stream
+    // pb_prod by (row block, column block) (pb_prod is a workspace of the matrix: launches on one matrix must not overlap)
     int             pb_blocks = 0, pb_span = 0, pb_split = 1;
     bool            pb_ordered = false;  // phase 2 adds the stream's pieces in stream order (same bits on every run)
     int            *pb_bnd = nullptr;   // [pb_blocks + 1] first row of each block
     int            *pb_pre = nullptr;   // [pb_blocks][pb_blocks + 1] per column block: flat position of each of its segments
-    unsigned       *pb_seg0 = nullptr;  // [pb_blocks][pb_blocks] per column block: array position of each of its segments
-    int64_t        *pb_bin = nullptr;   // [pb_blocks + 1] array position of each row block
+    unsigned       *pb_seg0 = nullptr;  // [pb_blocks][pb_blocks] per column block: position of each of its segments in the product stream
+    int64_t        *pb_bin = nullptr;   // [pb_blocks + 1] position of each row block in the product stream
+    int64_t        *pb_cbase = nullptr; // [pb_blocks] start of each column block's run of values / local columns
     unsigned short *pb_lcol = nullptr, *pb_lrow = nullptr;  // [nnz_off]
     double         *pb_prod = nullptr;  // [nnz_off]
 };

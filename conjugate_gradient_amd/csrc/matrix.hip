@@ -173,6 +173,7 @@ void cgh_matrix_free(cgh_matrix *m)
         cgh_free(m->pb_pre);
         cgh_free(m->pb_seg0);
         cgh_free(m->pb_bin);
+        cgh_free(m->pb_cbase);
         cgh_free(m->pb_lcol);
         cgh_free(m->pb_lrow);
         cgh_free(m->pb_prod);

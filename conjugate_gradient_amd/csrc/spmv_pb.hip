@@ -10,11 +10,13 @@
 //
 //   * rows (= columns: the matrices are structurally symmetric) are cut into BLOCKS of at most SPAN consecutive rows
 //     holding about equal numbers of entries (cgh_pb_partition_host, boundaries on multiples of 256 rows);
-//   * the entries are stored sorted by (block of the row b, block of the column s): 8-byte value, 2-byte column inside
-//     its block, 2-byte row inside its block -- 12 bytes per entry, as CSR.  The run of one (b, s) is a SEGMENT;
+//   * an entry is an 8-byte value, a 2-byte column inside its block and a 2-byte row inside its block -- 12 bytes, as
+//     CSR.  The entries of one (row block b, column block s) are a SEGMENT.  Values and local columns are stored
+//     sorted by (s, b) -- what one workgroup of phase 1 reads is ONE contiguous run --, local rows and the products
+//     sorted by (b, s) -- what one workgroup of phase 2 reads is one contiguous run;
 //   * phase 1, pb_expand, one workgroup per column block s: the block's part of x is staged in LDS (<= 128 KB), the
-//     workgroup streams its segments (b = 0..B-1: B contiguous runs), multiplies each value by its x from LDS and
-//     stores the product at the entry's own position of a product array (streaming, coalesced run by run);
+//     workgroup streams its run (segments b = 0..B-1), multiplies each value by its x from LDS and stores the
+//     product at the entry's position of the product stream (B runs of one segment each, coalesced run by run);
 //   * phase 2, pb_accumulate, one workgroup per row block b: the block's row sums live in LDS; the workgroup streams
 //     its products (ONE contiguous run) with their 2-byte local rows, adds them with LDS atomics, then writes
 //     y = diag*x + sum and the block's partial of x.y.
@@ -79,20 +81,23 @@ __global__ __launch_bounds__(256) void pb_entry_keys(int64_t n, int B, const int
     }
 }
 
-// sorted position q of segment `key` -> padded position pstart[key] + (q - start[key])
+// sorted position q of segment `key` = (b, s) -> position pstart[key] + (q - start[key]) of the product stream (local row
+// there), and position cbase[s] + pre[s][b] + (q - start[key]) of column block s's own run (value and local column there)
 __global__ __launch_bounds__(256) void pb_gather_sorted(int64_t nnz, int B, const unsigned *__restrict__ keys, const unsigned *__restrict__ idx,
                                                        const double *__restrict__ vals, const int *__restrict__ cols,
                                                        const int *__restrict__ rowid, const int *__restrict__ bnd,
                                                        const int64_t *__restrict__ start, const int64_t *__restrict__ pstart,
+                                                       const int *__restrict__ pre, const int64_t *__restrict__ cbase,
                                                        double *__restrict__ svals, unsigned short *__restrict__ lcol,
                                                        unsigned short *__restrict__ lrow)
 {
     for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < nnz; q += (int64_t)gridDim.x * 256) {
         const unsigned e = idx[q], key = keys[q];
         const int      b = (int)(key / (unsigned)B), s = (int)(key % (unsigned)B);
-        const int64_t  at = pstart[key] + (q - start[key]);
-        svals[at] = vals[e];
-        lcol[at] = (unsigned short)(cols[e] - bnd[s]);
+        const int64_t  in_seg = q - start[key];
+        const int64_t  at = pstart[key] + in_seg, at2 = cbase[s] + pre[(size_t)s * (B + 1) + b] + in_seg;
+        svals[at2] = vals[e];
+        lcol[at2] = (unsigned short)(cols[e] - bnd[s]);
         lrow[at] = (unsigned short)(rowid[e] - bnd[b]);
     }
 }
@@ -114,10 +119,10 @@ __global__ __launch_bounds__(256) void pb_seg_starts(int64_t nnz, int64_t nseg, 
 }
 
 // Per column block s, what pb_expand stages in LDS: pre[s][b] = entries of the segments (0..b-1, s) (flat position of
-// segment (b, s) inside the block's work), seg0[s][b] = where that segment starts in the arrays; bin_ptr[b] = start of
-// row block b.
+// segment (b, s) inside the block's work = inside its run of values and local columns), seg0[s][b] = where that segment
+// starts in the product stream; bin_ptr[b] = start of row block b there; col_total[s] = length of the block's run.
 __global__ __launch_bounds__(256) void pb_tables(int B, const int64_t *__restrict__ start, int *__restrict__ pre, unsigned *__restrict__ seg0,
-                                                int64_t *__restrict__ bin_ptr)
+                                                int64_t *__restrict__ bin_ptr, int64_t *__restrict__ col_total)
 {
     for (int s = blockIdx.x * 256 + threadIdx.x; s < B; s += gridDim.x * 256) {
         int run = 0;
@@ -128,6 +133,7 @@ __global__ __launch_bounds__(256) void pb_tables(int B, const int64_t *__restric
             run += (int)(start[(int64_t)b * B + s + 1] - a);
         }
         pre[(size_t)s * (B + 1) + B] = run;
+        col_total[s] = run;
         bin_ptr[s] = start[(int64_t)s * B];
         if (s == B - 1) bin_ptr[B] = start[(int64_t)B * B];
     }
@@ -147,9 +153,11 @@ typedef double d2_t __attribute__((ext_vector_type(2)));
 
 template <int SPAN, int UN = 4>
 __global__ __launch_bounds__(SPAN / 16) void pb_expand(int B, int split, const int *__restrict__ bnd, const int *__restrict__ pre,
-                                                      const unsigned *__restrict__ seg0, const double *__restrict__ vals,
+                                                      const unsigned *__restrict__ seg0, const int64_t *__restrict__ cbase,
+                                                      const double *__restrict__ vals,
                                                       const unsigned short *__restrict__ lcol, const double *__restrict__ x,
-                                                      double *__restrict__ prod, const int *__restrict__ done)
+                                                      double *__restrict__ prod, const int *__restrict__ done,
+                                                      long long *__restrict__ trace)
 {
     constexpr int T = SPAN / 16, NW = T / 64;
     __shared__ double   xs[SPAN];
@@ -157,6 +165,7 @@ __global__ __launch_bounds__(SPAN / 16) void pb_expand(int B, int split, const i
     __shared__ unsigned st_s[MAXB];
     if (done != nullptr && *done != 0) return;
     const int s = B - 1 - (int)(blockIdx.x / split), part = (int)(blockIdx.x % split);  // later blocks (denser rows) first
+    if (trace != nullptr && threadIdx.x == 0) trace[4 * blockIdx.x] = wall_clock64();  // tools/trace_pb.py
     const int r0 = bnd[s], cnt = bnd[s + 1] - r0;
     {
         // cnt <= SPAN = 16 T: the block's x in one round trip (a loop of load -> LDS store pays the memory latency 16 times
@@ -176,13 +185,17 @@ __global__ __launch_bounds__(SPAN / 16) void pb_expand(int B, int split, const i
         }
     }
     __syncthreads();
+    if (trace != nullptr && threadIdx.x == 0) trace[4 * blockIdx.x + 1] = wall_clock64();
     const int tot = pre_s[B];  // a multiple of PAD
+    vals += cbase[s];          // the block's own run: flat position f of its work is entry f of the run
+    lcol += cbase[s];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nchunks = (tot + 127) >> 7, units = split * NW, u = part * NW + wave;
     const int c0 = (int)((int64_t)nchunks * u / units), c1 = (int)((int64_t)nchunks * (u + 1) / units);
     int       f = c0 * 128;
     const int fend = c1 * 128 < tot ? c1 * 128 : tot;
+    if (trace != nullptr && lane == 0) trace[4 * blockIdx.x + 3] = tot;
     if (f >= fend) return;
     int b;  // uniform cursor: pre_s[b] <= f (and f < tot = pre_s[B])
     {
@@ -211,10 +224,10 @@ __global__ __launch_bounds__(SPAN / 16) void pb_expand(int B, int split, const i
             pc.c[q] = 0;
             pc.k[q] = 0;
             if (pc.act[q]) {
+                pc.v[q] = __builtin_nontemporal_load((const d2_t *)(vals + fu));
+                pc.c[q] = __builtin_nontemporal_load((const unsigned *)(lcol + fu));
                 while (fu >= pre_s[bu + 1]) ++bu;  // fu < tot = pre_s[B]: stops at bu <= B - 1
-                pc.k[q] = st_s[bu] + (unsigned)(fu - pre_s[bu]);
-                pc.v[q] = __builtin_nontemporal_load((const d2_t *)(vals + pc.k[q]));
-                pc.c[q] = __builtin_nontemporal_load((const unsigned *)(lcol + pc.k[q]));
+                pc.k[q] = st_s[bu] + (unsigned)(fu - pre_s[bu]);  // where the products of this pair go
             }
         }
         b = __builtin_amdgcn_readfirstlane(bu);  // lane 0's cursor: its last position is below the next piece's first
@@ -238,6 +251,7 @@ __global__ __launch_bounds__(SPAN / 16) void pb_expand(int B, int split, const i
         fetch(pa, f + 2 * 128 * UN);
         emit(pb);
     }
+    if (trace != nullptr && lane == 0) atomicMax((unsigned long long *)&trace[4 * blockIdx.x + 2], (unsigned long long)wall_clock64());
 }
 
 // pb_accumulate.  One workgroup per row block: row sums in LDS, products streamed from the block's one contiguous run.
@@ -251,7 +265,7 @@ __global__ __launch_bounds__(SPAN / 16) void pb_accumulate(int B, const int *__r
                                                           const double *__restrict__ prod, const unsigned short *__restrict__ lrow,
                                                           const double *__restrict__ diag, const double *__restrict__ x,
                                                           double *__restrict__ y, double *__restrict__ partials,
-                                                          const int *__restrict__ done)
+                                                          const int *__restrict__ done, long long *__restrict__ trace)
 {
     constexpr int T = SPAN / 16, NW = T / 64;
     __shared__ double acc[SPAN];
@@ -259,6 +273,7 @@ __global__ __launch_bounds__(SPAN / 16) void pb_accumulate(int B, const int *__r
     __shared__ int    ticket;
     if (done != nullptr && *done != 0) return;
     const int b = B - 1 - (int)blockIdx.x;
+    if (trace != nullptr && threadIdx.x == 0) trace[4 * blockIdx.x] = wall_clock64();
     const int r0 = bnd[b], cnt = bnd[b + 1] - r0;
     for (int i = threadIdx.x; i < cnt; i += T) acc[i] = 0.0;
     if (threadIdx.x == 0) ticket = 0;
@@ -315,6 +330,10 @@ __global__ __launch_bounds__(SPAN / 16) void pb_accumulate(int B, const int *__r
         }
     }
     __syncthreads();
+    if (trace != nullptr && threadIdx.x == 0) {
+        trace[4 * blockIdx.x + 1] = wall_clock64();
+        trace[4 * blockIdx.x + 3] = k1 - k0;
+    }
     double local = 0.0;
     // diag and x are read once, here; cnt <= SPAN = 16 T: four rows per lane and round trip
     for (int i0 = threadIdx.x; i0 < cnt; i0 += 4 * T) {
@@ -335,6 +354,8 @@ __global__ __launch_bounds__(SPAN / 16) void pb_accumulate(int B, const int *__r
             }
         }
     }
+    if (trace != nullptr && (threadIdx.x & 63) == 0)
+        atomicMax((unsigned long long *)&trace[4 * blockIdx.x + 2], (unsigned long long)wall_clock64());
     if constexpr (DOT) {
         local = wave_sum(local);
         if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = local;
@@ -347,15 +368,20 @@ __global__ __launch_bounds__(SPAN / 16) void pb_accumulate(int B, const int *__r
     }
 }
 
+// workgroup time stamps of one SpMV (tools/trace_pb.py): 4 words per workgroup {start, operands staged / stream done, end,
+// entries}, pb_expand's from word 0, pb_accumulate's from word 4 * 4096; NULL = off
+long long *g_pb_trace = nullptr;
+
 template <int SPAN>
 void launch(const cgh_matrix *m, const double *x, double *y, double *dot_partials, const int *done, hipStream_t s)
 {
     const int B = m->pb_blocks, split = m->pb_split > 0 ? m->pb_split : 1;
     hipLaunchKernelGGL((pb_expand<SPAN>), dim3(B * split), dim3(SPAN / 16), 0, s, B, split, (const int *)m->pb_bnd, (const int *)m->pb_pre,
-                       (const unsigned *)m->pb_seg0, (const double *)m->vals, (const unsigned short *)m->pb_lcol, x, m->pb_prod, done);
+                       (const unsigned *)m->pb_seg0, (const int64_t *)m->pb_cbase, (const double *)m->vals, (const unsigned short *)m->pb_lcol, x, m->pb_prod, done, B * split <= 4096 ? g_pb_trace : nullptr);
 #define PB_ACC(D, O)                                                                                                                \
     hipLaunchKernelGGL((pb_accumulate<SPAN, D, O>), dim3(B), dim3(SPAN / 16), 0, s, B, (const int *)m->pb_bnd, (const int64_t *)m->pb_bin, \
-                       (const double *)m->pb_prod, (const unsigned short *)m->pb_lrow, (const double *)m->diag, x, y, dot_partials, done)
+                       (const double *)m->pb_prod, (const unsigned short *)m->pb_lrow, (const double *)m->diag, x, y, dot_partials, done,       \
+                       g_pb_trace ? g_pb_trace + 4 * 4096 : nullptr)
     if (dot_partials && m->pb_ordered) PB_ACC(true, true);
     else if (dot_partials) PB_ACC(true, false);
     else if (m->pb_ordered) PB_ACC(false, true);
@@ -489,19 +515,25 @@ static cgh_matrix *cgh_pb_from_csr_impl(cgh_matrix *csr)
             m->pb_pre = (int *)cgh_alloc(sizeof(int) * (size_t)(B * (B + 1)));
             m->pb_seg0 = (unsigned *)cgh_alloc(sizeof(unsigned) * (size_t)nseg);
             m->pb_bin = (int64_t *)cgh_alloc(sizeof(int64_t) * (size_t)(B + 1));
-            ok = m->vals && m->pb_lcol && m->pb_lrow && m->pb_prod && m->pb_pre && m->pb_seg0 && m->pb_bin;
+            m->pb_cbase = (int64_t *)cgh_alloc(sizeof(int64_t) * (size_t)(B + 1));
+            ok = m->vals && m->pb_lcol && m->pb_lrow && m->pb_prod && m->pb_pre && m->pb_seg0 && m->pb_bin && m->pb_cbase;
         }
         if (ok)  // pads: value 0, column 0, row 0xffff (skipped by pb_accumulate)
             ok = hipMemsetAsync(m->vals, 0, sizeof(double) * ep, s) == hipSuccess &&
                  hipMemsetAsync(m->pb_lcol, 0, sizeof(unsigned short) * ep, s) == hipSuccess &&
                  hipMemsetAsync(m->pb_lrow, 0xff, sizeof(unsigned short) * ep, s) == hipSuccess;
         if (ok) {
-            if (nnz > 0)
+            // tables first: the gather needs each column block's run (its start = the totals of the blocks before it)
+            int64_t total = 0;
+            hipLaunchKernelGGL(pb_tables, dim3(grid_for(B)), dim3(256), 0, s, (int)B, (const int64_t *)pstart.p, m->pb_pre, m->pb_seg0, m->pb_bin,
+                               m->pb_cbase);
+            ok = hipGetLastError() == hipSuccess && cgh_exclusive_scan_i64(m->pb_cbase, m->pb_cbase, B, &total, s) == CGH_OK && total == epad;
+            if (ok && nnz > 0)
                 hipLaunchKernelGGL(pb_gather_sorted, dim3(grid_for(nnz)), dim3(256), 0, s, nnz, (int)B, (const unsigned *)k1.p,
                                    (const unsigned *)i1.p, (const double *)csr->vals, (const int *)csr->cols, (const int *)rid.p,
-                                   (const int *)m->pb_bnd, (const int64_t *)start.p, (const int64_t *)pstart.p, m->vals, m->pb_lcol, m->pb_lrow);
-            hipLaunchKernelGGL(pb_tables, dim3(grid_for(B)), dim3(256), 0, s, (int)B, (const int64_t *)pstart.p, m->pb_pre, m->pb_seg0, m->pb_bin);
-            ok = hipGetLastError() == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
+                                   (const int *)m->pb_bnd, (const int64_t *)start.p, (const int64_t *)pstart.p, (const int *)m->pb_pre,
+                                   (const int64_t *)m->pb_cbase, m->vals, m->pb_lcol, m->pb_lrow);
+            ok = ok && hipGetLastError() == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
         }
     }
     if (ok) {
@@ -527,6 +559,8 @@ cgh_matrix *cgh_pb_from_csr(cgh_matrix *csr)
         return nullptr;  // (csr may be lost with it: the process is out of host memory)
     }
 }
+
+extern "C" void cgh_pb_set_trace(void *dev_8_x_4096_words) { g_pb_trace = (long long *)dev_8_x_4096_words; }
 
 extern "C" int cgh_config_pb(int span_bits, int64_t target_entries, int split, int ordered)
 {
