@@ -94,7 +94,7 @@ struct cgh_matrix {
     // the 2-byte local columns sorted by (column block, row block), the 2-byte local rows and the launch's product stream
     // pb_prod by (row block, column block) (pb_prod is a workspace of the matrix: launches on one matrix must not overlap)
     int             pb_blocks = 0, pb_span = 0, pb_split = 1;
-    bool            pb_ordered = false;  // phase 2 adds the stream's pieces in stream order (same bits on every run)
+    bool            pb_ordered = true;   // phase 2 adds the stream's pieces in stream order (same bits on every run)
     int            *pb_bnd = nullptr;   // [pb_blocks + 1] first row of each block
     int            *pb_pre = nullptr;   // [pb_blocks][pb_blocks + 1] per column block: flat position of each of its segments
     unsigned       *pb_seg0 = nullptr;  // [pb_blocks][pb_blocks] per column block: position of each of its segments in the product stream
@@ -141,7 +141,7 @@ struct cgh_config {
     int pb_span_bits = 14;      // CGH_PB_SPAN_BITS: log2 of the most rows a block of the two-phase layout holds (13 | 14)
     int64_t pb_target_entries = 131072; // CGH_PB_TARGET: entries per block the partition aims at
     int pb_split = 1;           // CGH_PB_SPLIT: workgroups sharing one column block in phase 1
-    int pb_ordered = 0;         // CGH_PB_ORDERED: 1 = phase 2 adds in stream order (same bits on every run, +14 % time); 0 = as the LDS atomics retire
+    int pb_ordered = 1;         // CGH_PB_ORDERED: 1 = phase 2 adds in stream order (same bits on every run; the default); 0 = as the LDS atomics retire (2 % faster)
 };
 extern cgh_config g_cfg;
 // What a cgh_config_* setter writes: the field of g_cfg now, and again after every later cgh_init / cgh_config_reload

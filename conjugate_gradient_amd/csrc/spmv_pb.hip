@@ -22,10 +22,11 @@
 //     y = diag*x + sum and the block's partial of x.y.
 //
 // Bytes per entry: 10 read + 8 written in phase 1, 10 read in phase 2 = 28 against the 12 algorithmic ones; no access
-// to HBM or L2 is random.  Throughput layout only: a row's products are added in the order the LDS atomics retire
-// (not the reference's order, and not the same from run to run: results agree with the exact-order kernels to a few
-// ulps of the row's magnitude) -- or, ORDERED (cgh_config_pb / CGH_PB_ORDERED=1), in the order of the product stream:
-// the same bits on every run, for 14 % more time.  Strict solves and exact_rows callers keep CGH_LAYOUT_CSR / ELL.
+// to HBM or L2 is random.  Throughput layout only: a row's products are added in the order of the product stream
+// (ORDERED, the default: the same bits on every run) or, cgh_config_pb(.., ordered = 0) / CGH_PB_ORDERED=0, in the order
+// the LDS atomics retire (2 % faster, last bits differ from run to run) -- never the reference's order (results agree
+// with the exact-order kernels to a few ulps of the row's magnitude).  Strict solves and exact_rows callers keep
+// CGH_LAYOUT_CSR / ELL.
 #include <algorithm>
 #include <exception>
 #include <vector>
@@ -259,7 +260,8 @@ __global__ __launch_bounds__(SPAN / 16) void pb_expand(int B, int split, const i
 // ticket names its piece, and hands the ticket on behind them (LDS executes a CU's instructions in arrival order, so whoever
 // reads the new ticket is behind those adds; lanes of one instruction that meet on a row are applied in lane order).  The
 // order of additions into a row is then fixed by the layout: same bits on every run.  The loads of a piece are in flight
-// while its wave waits for its turn.
+// while its wave waits for its turn, and everything but the adds themselves is done before the turn (the first version
+// computed addresses and skipped pads by branches inside it: phase 2 229 us on config 5; now 170, against 161 unordered).
 template <int SPAN, bool DOT, bool ORDERED>
 __global__ __launch_bounds__(SPAN / 16) void pb_accumulate(int B, const int *__restrict__ bnd, const int64_t *__restrict__ bin_ptr,
                                                           const double *__restrict__ prod, const unsigned short *__restrict__ lrow,
@@ -268,7 +270,7 @@ __global__ __launch_bounds__(SPAN / 16) void pb_accumulate(int B, const int *__r
                                                           const int *__restrict__ done, long long *__restrict__ trace)
 {
     constexpr int T = SPAN / 16, NW = T / 64;
-    __shared__ double acc[SPAN];
+    __shared__ double acc[SPAN + 64];  // the block's row sums; behind them one slot per lane where the pads' products go
     __shared__ double red[NW];
     __shared__ int    ticket;
     if (done != nullptr && *done != 0) return;
@@ -276,6 +278,7 @@ __global__ __launch_bounds__(SPAN / 16) void pb_accumulate(int B, const int *__r
     if (trace != nullptr && threadIdx.x == 0) trace[4 * blockIdx.x] = wall_clock64();
     const int r0 = bnd[b], cnt = bnd[b + 1] - r0;
     for (int i = threadIdx.x; i < cnt; i += T) acc[i] = 0.0;
+    if (threadIdx.x < 64) acc[SPAN + threadIdx.x] = 0.0;
     if (threadIdx.x == 0) ticket = 0;
     __syncthreads();
     const int64_t k0 = bin_ptr[b], k1 = bin_ptr[b + 1];  // both ends are multiples of PAD
@@ -297,14 +300,26 @@ __global__ __launch_bounds__(SPAN / 16) void pb_accumulate(int B, const int *__r
                     r[q] = __builtin_nontemporal_load((const unsigned *)(lrow + kq));
                 }
             }
+            // Everything that is not an LDS add happens BEFORE the wave's turn: the addresses (pads go to the lane's own
+            // spare slot: no branch per entry inside the turn) need the last local rows loaded, and loads return in order,
+            // so the products are in registers too.  What the other waves wait for is then 2 UN adds and the hand-over.
+            unsigned a0[UN], a1[UN];
+#pragma unroll
+            for (int q = 0; q < UN; ++q) {
+                const unsigned lo = r[q] & 0xffffu, hi = r[q] >> 16;
+                a0[q] = (lo != 0xffffu ? lo : (unsigned)(SPAN + lane)) * 8u;  // byte offsets into acc
+                a1[q] = (hi != 0xffffu ? hi : (unsigned)(SPAN + lane)) * 8u;
+                // (pinned here: the compiler would otherwise sink the wait for the loads and this arithmetic into the turn)
+                asm volatile("" : "+v"(a0[q]), "+v"(a1[q]), "+v"(p[q]));
+            }
             // acquire / release (an lgkmcnt wait each on gfx950): the adds below stay behind the ticket they wait for and
             // ahead of the one they hand on, whatever the compiler would like to do with relaxed atomics to other addresses
             while (__hip_atomic_load(&ticket, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != (int)pc) {
             }
 #pragma unroll
             for (int q = 0; q < UN; ++q) {
-                if ((r[q] & 0xffffu) != 0xffffu) unsafeAtomicAdd(&acc[r[q] & 0xffffu], p[q].x);
-                if ((r[q] >> 16) != 0xffffu) unsafeAtomicAdd(&acc[r[q] >> 16], p[q].y);
+                unsafeAtomicAdd((double *)((char *)acc + a0[q]), p[q].x);
+                unsafeAtomicAdd((double *)((char *)acc + a1[q]), p[q].y);
             }
             if (lane == 0) __hip_atomic_store(&ticket, (int)pc + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         }

@@ -72,8 +72,8 @@ enum {
     CGH_LAYOUT_PB = 5     /* two-phase SpMV (propagation blocking; throughput layout for scattered columns, BASELINE config 5):
                              entries sorted by (row block, column block) with 2-byte local indices; phase 1 multiplies by x
                              staged in LDS and streams the products, phase 2 adds them into row sums held in LDS -- no random
-                             access leaves the CU; a row's sum is added in no fixed order unless cgh_config_pb asks for one (agrees with the
-                             reference to rounding, not bit for bit) */
+                             access leaves the CU; a row's sum is added in the order of the product stream (the same bits on every
+                             run; not the reference's order: agrees with it to rounding, not bit for bit) */
 };
 
 /* Host slot-major full ELL (what coo_to_ell_symmetric_full_colmajor produced) -> device. */
@@ -111,8 +111,8 @@ int     cgh_config_csrb(int rows_per_wave_block, int slab_bits, int wgs_per_cu, 
 int     cgh_config_sell_sigma(int sigma_rows);
 /* Tuning of the CGH_LAYOUT_PB matrices constructed after the call (0 keeps): log2 of the most rows per block (13 | 14), entries
  * per block the partition aims at, workgroups sharing one column block in phase 1 (1..16); ordered: 1 = phase 2 adds the
- * products in the order of the stream (the same bits on every run, about 14 % slower), 0 = as the LDS atomics retire (the
- * default), < 0 keeps. */
+ * products in the order of the stream (the same bits on every run; the default), 0 = as the LDS atomics retire (about 2 %
+ * faster, results differ from run to run in the last bits), < 0 keeps. */
 int     cgh_config_pb(int span_bits, int64_t target_entries, int split, int ordered);
 /* Throughput-mode (strict = 0) solves of ELL matrices of at most 131 072 rows and at most 8 slots run their iterations as
  * ONE resident launch per batch (csrc/cg_persistent.h: workgroups keep their rows in registers and exchange p and the

@@ -1,7 +1,8 @@
 """GPU parity of CGH_LAYOUT_PB, the two-phase (propagation-blocking) SpMV added for BASELINE config 5 (spmv_pb.hip).
 
 A throughput layout: phase 1 multiplies every stored value by its x (staged in LDS) and streams the products, phase 2
-adds them into row sums held in LDS with LDS atomics -- a row's products are added in no fixed order.  The reference's
+adds them into row sums held in LDS with LDS atomics -- in the order of the product stream (the default since the end of
+round 3: the same bits on every run) or, ordered = 0, as the atomics retire; neither is the reference's order.  The reference's
 SpMV for such a matrix is mv_csr_symmetric / mv_coo_symmetric (src/csr.c:190-229, src/coo.c:202-233); the bar here is
 the throughput-mode bar of the north star: every y_i within a few ulps of sum_j |a_ij x_j| of the reference's value
 (goldens produced by oracle/_ref), CG iterations within +-1 and the residual trajectory within 1e-10 relative over the
@@ -27,7 +28,7 @@ def cga():
     import conjugate_gradient_amd as m
     m.init(0)
     yield m
-    m.config_pb(14, 131072, 1, 0)
+    m.check(m.lib().cgh_config_reset())
 
 
 def _abs_bound(n, diag, vals, rows, cols, x):
@@ -38,12 +39,13 @@ def _abs_bound(n, diag, vals, rows, cols, x):
     return s
 
 
+@pytest.mark.parametrize("ordered", [1, 0])
 @pytest.mark.parametrize("cfg", PB_CONFIGS)
 @pytest.mark.parametrize("tag", GOLDENS)
-def test_pb_spmv_matches_reference_to_rounding(cga, tag, cfg):
+def test_pb_spmv_matches_reference_to_rounding(cga, tag, cfg, ordered):
     s, g = inputs(tag), golden(tag)
     n = s["n"]
-    cga.config_pb(*cfg)
+    cga.config_pb(*cfg, ordered)
     A = cga.Matrix.from_coo(n, s["diag"], s["upper"], s["rows"], s["cols"], cga.LAYOUT_PB)
     assert (A.n, A.K, A.nnz_offdiag, A.layout) == (n, int(g["K_full"]), 2 * s["U"], cga.LAYOUT_PB)
     x = cga.DeviceVector.from_host(g["x_probe"]); y = cga.DeviceVector(n)
@@ -59,7 +61,7 @@ def test_pb_spmv_matches_reference_to_rounding(cga, tag, cfg):
 def test_pb_skewed_rows_and_shapes(cga, cfg):
     """power-law rows up to 300 entries, n not a multiple of the 256-row partition unit, then the edge shapes: fewer
     rows than one unit, a diagonal matrix (no entries at all), one dense row"""
-    cga.config_pb(*cfg)
+    cga.config_pb(*cfg, 1)
     n, max_len, seed = 6001, 300, 0x5EED0005
     s = foamio.powerlaw_coo(n, max_len, seed)
     rng = np.random.default_rng(3)
@@ -82,10 +84,11 @@ def test_pb_skewed_rows_and_shapes(cga, cfg):
         assert np.allclose(yd.to_host(), want2, rtol=1e-14, atol=0), (n2, cfg)
 
 
-def test_pb_pads_do_not_leak_non_finite_x(cga):
+@pytest.mark.parametrize("ordered", [1, 0])
+def test_pb_pads_do_not_leak_non_finite_x(cga, ordered):
     """segments are padded with (value 0, column 0 of the block) entries whose products are never added: an infinite or
     NaN x[0] must reach only the rows that really have a column-0 entry (and row 0 through its diagonal)"""
-    cga.config_pb(14, 300, 1)
+    cga.config_pb(14, 300, 1, ordered)   # (ordered: the pads' products go to spare LDS slots; not: they are skipped)
     n = 1500
     s = foamio.powerlaw_coo(n, 40, 0x5EED0005)
     diag = np.full(n, 50.0); xh = np.ones(n); xh[0] = np.inf; xh[256] = np.nan
@@ -103,7 +106,8 @@ def test_pb_pads_do_not_leak_non_finite_x(cga):
 @pytest.mark.parametrize("cfg", PB_CONFIGS)
 def test_pb_ordered_mode_gives_the_same_bits_every_run(cga, cfg):
     """cgh_config_pb(..., ordered=1): phase 2 adds the product stream's pieces in stream order -- SpMV output and a whole
-    CG trajectory bit-identical from run to run (the default order, as the LDS atomics retire, is not), same accuracy"""
+    CG trajectory bit-identical from run to run (the order in which the LDS atomics retire, ordered=0, is not), same accuracy.
+    The default since the end of round 3."""
     cga.config_pb(*cfg, 1)
     n, max_len, seed = 40001, 500, 0x5EED0005
     s = foamio.powerlaw_coo(n, max_len, seed)
@@ -123,7 +127,6 @@ def test_pb_ordered_mode_gives_the_same_bits_every_run(cga, cfg):
     rep, hist = cga.cg_solve(A, b, xs, max_iter=60, tol=1e-9, strict=0)
     rep2, hist2 = cga.cg_solve(A, b, xs, max_iter=60, tol=1e-9, strict=0)
     assert rep2.ret == rep.ret and hist.tobytes() == hist2.tobytes()
-    cga.config_pb(0, 0, 0, 0)
 
 
 @pytest.mark.parametrize("tag", ["cylinder_2000", "poisson7_32x24x20", "poisson27_12x10x8"])
