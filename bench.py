@@ -332,7 +332,8 @@ def main():
         what = ("%s: SPD matrix with power-law row lengths (Pareto exponent 2, 1..%d entries per row, realised max %d, mean %.2f), "
                 "columns uniformly random, %d rows, two-phase (propagation-blocking) layout, unpreconditioned CG" % (args.workload, wl[2], A.K, A.nnz_offdiag / n, n))
         kernel = ("pb_expand + pb_accumulate (two-phase SpMV + p.Ap partials: 12 bytes per stored entry; phase 1 multiplies by x staged in "
-                  "LDS and streams the products through HBM, phase 2 adds them into row sums held in LDS; achieved = algorithmic bytes / "
+                  "LDS and streams the products through HBM, phase 2 adds them into row sums held in LDS in the order of the stream -- the same "
+                  "bits on every run; achieved = algorithmic bytes / "
                   "time of BOTH launches; HIP events around every 4th SpMV of the timed region)")
     else:
         what = "%s: 3-D %d-point Poisson %dx%dx%d, %d rows, slot-major ELL K=%d, unpreconditioned CG" % (args.workload, points, nx, ny, nz, n, A.K)
