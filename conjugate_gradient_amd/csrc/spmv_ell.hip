@@ -62,6 +62,19 @@ __device__ __forceinline__ i2_t load_cols(const void *__restrict__ cols, const i
     }
 }
 
+// Where (slot s, row i0) lives.  Slot-major: s*n + i0 (the reference's column-major ELL).  DICT == 3, wide banded rows: the
+// derived "tile-blocked" copy -- the 512 rows of a tile keep their K slots together, slot after slot, so a workgroup reads
+// ONE contiguous run of K*4 KiB (+ the code words) per tile instead of K runs that lie n*8 bytes apart (26 streams 134 MB
+// apart at 256^3, 1 GiB apart at 512^3: one page per stream and wave).  `per_tile` = slots (or code words) per row.
+template <int DICT>
+__device__ __forceinline__ int64_t slot_at(int64_t n, int per_tile, int s, int64_t i0)
+{
+    if constexpr (DICT == 3)
+        return ((i0 >> 9) * per_tile + s) * 512 + (i0 & 511);
+    else
+        return (int64_t)s * n + i0;
+}
+
 // x[c] for a stored column id (pads, c < 0, read the row's own entry and are discarded by the caller).  HALO: ids from
 // hl.nl on are halo entries of a multi-GPU block, read from the deposit buffer the neighbours write into (halo_ll.h) --
 // the wait for a neighbour's push happens here, in the lanes that need the entry, and nowhere else.
@@ -124,16 +137,16 @@ __global__ __launch_bounds__(CGH_BLOCK) void spmv_ell_r2(int64_t n, int Krt, con
         if constexpr (KT > 0) {
             d2_t v[KT];
             i2_t c[KT];
-            if constexpr (DICT == 2) {
+            if constexpr (DICT >= 2) {
                 // wide rows: the codes of 4 slots of one row share a 32-bit word (word q of row i at q*n+i), so a lane
                 // fetches 8 bytes per 4 slots of its row pair instead of four 2-byte loads
                 constexpr int NW = (KT + 3) / 4;
                 u2_t          w[NW];
 #pragma unroll
                 for (int q = 0; q < NW; ++q)
-                    w[q] = stream_load<NT>(reinterpret_cast<const u2_t *>(reinterpret_cast<const unsigned *>(cols) + (int64_t)q * n + i0));
+                    w[q] = stream_load<NT>(reinterpret_cast<const u2_t *>(reinterpret_cast<const unsigned *>(cols) + slot_at<DICT>(n, NW, q, i0)));
 #pragma unroll
-                for (int s = 0; s < KT; ++s) v[s] = stream_load<NT>(reinterpret_cast<const d2_t *>(vals + (int64_t)s * n + i0));
+                for (int s = 0; s < KT; ++s) v[s] = stream_load<NT>(reinterpret_cast<const d2_t *>(vals + slot_at<DICT>(n, KT, s, i0)));
 #pragma unroll
                 for (int s = 0; s < KT; ++s) {
                     const int c0 = (w[s >> 2].x >> (8 * (s & 3))) & 0xff, c1 = (w[s >> 2].y >> (8 * (s & 3))) & 0xff;
@@ -171,16 +184,16 @@ __global__ __launch_bounds__(CGH_BLOCK) void spmv_ell_r2(int64_t n, int Krt, con
 #pragma unroll 4
             for (int s = 0; s < K; ++s) {
                 i2_t c;
-                if constexpr (DICT == 2) {
+                if constexpr (DICT >= 2) {
                     if ((s & 3) == 0)
-                        w = stream_load<NT>(reinterpret_cast<const u2_t *>(reinterpret_cast<const unsigned *>(cols) + (int64_t)(s >> 2) * n + i0));
+                        w = stream_load<NT>(reinterpret_cast<const u2_t *>(reinterpret_cast<const unsigned *>(cols) + slot_at<DICT>(n, (K + 3) / 4, s >> 2, i0)));
                     const int c0 = (w.x >> (8 * (s & 3))) & 0xff, c1 = (w.y >> (8 * (s & 3))) & 0xff;
                     c.x = c0 != 255 ? (int)i0 + tab[c0] : -1;
                     c.y = c1 != 255 ? (int)i0 + 1 + tab[c1] : -1;
                 } else {
                     c = load_cols<NT, DICT>(cols, tab, n, s, i0);
                 }
-                const d2_t    v = stream_load<NT>(reinterpret_cast<const d2_t *>(vals + (int64_t)s * n + i0));
+                const d2_t    v = stream_load<NT>(reinterpret_cast<const d2_t *>(vals + slot_at<DICT>(n, K, s, i0)));
                 const double  g0 = gather_x<HALO>(x, c.x, i0, hl);
                 const double  g1 = gather_x<HALO>(x, c.y, i0, hl);
                 const double  t0 = madd_rn(a0, v.x, g0);
@@ -379,6 +392,30 @@ __global__ __launch_bounds__(256) void dict_encode_packed(int64_t n, int K, cons
     }
 }
 
+// tile-blocked copies for wide rows (slot_at<3>): the values, and the packed code words written where the kernel reads them.
+// Rows beyond n in the last tile hold zeros / pads (never read: the kernel's row pairs end at n).
+__global__ __launch_bounds__(256) void ell_block_vals(int64_t n, int K, const double *__restrict__ vals, double *__restrict__ out)
+{
+    const int64_t total = ((n + 511) >> 9) * (int64_t)K * 512;
+    for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < total; k += (int64_t)gridDim.x * 256) {
+        const int64_t tile = k / ((int64_t)K * 512);
+        const int     s = (int)((k >> 9) % K);
+        const int64_t i = tile * 512 + (k & 511);
+        out[k] = i < n ? vals[(int64_t)s * n + i] : 0.0;
+    }
+}
+
+__global__ __launch_bounds__(256) void ell_block_words(int64_t n, int NW, const unsigned *__restrict__ words, unsigned *__restrict__ out)
+{
+    const int64_t total = ((n + 511) >> 9) * (int64_t)NW * 512;
+    for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < total; k += (int64_t)gridDim.x * 256) {
+        const int64_t tile = k / ((int64_t)NW * 512);
+        const int     q = (int)((k >> 9) % NW);
+        const int64_t i = tile * 512 + (k & 511);
+        out[k] = i < n ? words[(int64_t)q * n + i] : 0xffffffffu;
+    }
+}
+
 std::mutex g_dict_mutex;
 
 // Build m->cols8 / m->off_tab if the matrix has at most 255 distinct diagonals.  Synchronises the stream.  Called under
@@ -432,8 +469,33 @@ void ell_dict_try_build(const cgh_matrix *m, hipStream_t s)
         cgh_ell_dict_free(m);
         return;
     }
+    int final_mode = mode;
+    if (mode == 2 && g_cfg.ell_blocked) {
+        // wide rows: tile-blocked copies of the values and of the code words (slot_at<3>).  The slot-major values stay (other
+        // paths read them: the one-row-per-lane kernel, int32 columns, downloads); if the copy cannot be had, the packed
+        // slot-major layout serves.
+        const int     NW = (m->K + 3) / 4;
+        const int64_t tiles = (m->n + 511) >> 9;
+        double       *vb = (double *)cgh_alloc(sizeof(double) * (size_t)tiles * (size_t)m->K * 512);
+        unsigned     *wb = (unsigned *)cgh_alloc(sizeof(unsigned) * (size_t)tiles * (size_t)NW * 512);
+        bool          okb = vb && wb;
+        if (okb) {
+            hipLaunchKernelGGL(ell_block_vals, dim3(grid), dim3(256), 0, s, m->n, m->K, (const double *)m->vals, vb);
+            hipLaunchKernelGGL(ell_block_words, dim3(grid), dim3(256), 0, s, m->n, NW, reinterpret_cast<const unsigned *>(m->cols8), wb);
+            okb = hipGetLastError() == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
+        }
+        if (okb) {
+            cgh_free(m->cols8);
+            m->cols8 = reinterpret_cast<unsigned char *>(wb);
+            m->vals_blk = vb;
+            final_mode = 3;
+        } else {
+            cgh_free(vb);
+            cgh_free(wb);
+        }
+    }
     m->n_offsets = count;
-    m->dict_mode = mode;
+    m->dict_mode = final_mode;
     done.state = 1;
 }
 
@@ -445,13 +507,21 @@ extern "C" int cgh_matrix_dict_offsets(const cgh_matrix *m)
     return m->dict_state == 0 ? -1 : (m->dict_state == 1 ? m->n_offsets : 0);
 }
 
+extern "C" int cgh_matrix_dict_mode(const cgh_matrix *m)
+{
+    if (!m || m->layout != CGH_LAYOUT_ELL) return 0;
+    return __atomic_load_n(&m->dict_state, __ATOMIC_ACQUIRE) == 1 ? m->dict_mode : 0;
+}
+
 void cgh_ell_dict_free(const cgh_matrix *m)
 {
     if (!m) return;
     cgh_free(m->cols8);
     cgh_free(m->off_tab);
+    cgh_free(m->vals_blk);
     m->cols8 = nullptr;
     m->off_tab = nullptr;
+    m->vals_blk = nullptr;
     if (m->dict_state == 1) m->dict_state = 2;
 }
 
@@ -549,7 +619,10 @@ int cgh_launch_spmv_ell_range2(const cgh_matrix *m, const double *x, double *y, 
     if (ell_vector_path(m, x, y) && rb % 2 == 0 && re % 2 == 0 && rb2 % 2 == 0 && re2 % 2 == 0) {
         // strict mode's per-cell sums of x.y instead of per-workgroup partials
         if (cell_sums != nullptr && dot_partials == nullptr && rb == 0 && re == m->n && re2 <= rb2 && m->n % 128 == 0) {
-            if (m->dict_state == 1 && m->dict_mode == 2)
+            if (m->dict_state == 1 && m->dict_mode == 3)
+                launch_r2<2, VAR_DEFAULT, 3>(m->K, grid, s, m->n, m->diag, m->vals_blk, m->cols8, m->off_tab, x, y, cell_sums, done,
+                                             rb, re, rb2, re2, rev);
+            else if (m->dict_state == 1 && m->dict_mode == 2)
                 launch_r2<2, VAR_DEFAULT, 2>(m->K, grid, s, m->n, m->diag, m->vals, m->cols8, m->off_tab, x, y, cell_sums, done,
                                              rb, re, rb2, re2, rev);
             else if (m->dict_state == 1)
@@ -570,12 +643,20 @@ int cgh_launch_spmv_ell_range2(const cgh_matrix *m, const double *x, double *y, 
             const int dvar = (forced == 1 || forced == 3 || forced == 11) ? forced : (cgh_fits_llc(m, 1.0) ? 1 : VAR_DEFAULT);
 #define CGH_ELL_DICT_LAUNCH(V, MODE)                                                                                       \
     if (dot_partials)                                                                                                      \
-        launch_r2<true, V, MODE>(m->K, grid, s, m->n, m->diag, m->vals, m->cols8, m->off_tab, x, y, dot_partials, done, rb, re, \
-                                 rb2, re2, rev);                                                                           \
+        launch_r2<true, V, MODE>(m->K, grid, s, m->n, m->diag, MODE == 3 ? m->vals_blk : m->vals, m->cols8, m->off_tab, x, y,  \
+                                 dot_partials, done, rb, re, rb2, re2, rev);                                               \
     else                                                                                                                   \
-        launch_r2<false, V, MODE>(m->K, grid, s, m->n, m->diag, m->vals, m->cols8, m->off_tab, x, y, nullptr, done, rb, re, rb2, \
-                                  re2, rev);
-            if (m->dict_mode == 2) {
+        launch_r2<false, V, MODE>(m->K, grid, s, m->n, m->diag, MODE == 3 ? m->vals_blk : m->vals, m->cols8, m->off_tab, x, y, \
+                                  nullptr, done, rb, re, rb2, re2, rev);
+            if (m->dict_mode == 3) {
+                if (dvar == 3) {
+                    CGH_ELL_DICT_LAUNCH(3, 3)
+                } else if (dvar == 1) {
+                    CGH_ELL_DICT_LAUNCH(1, 3)
+                } else {
+                    CGH_ELL_DICT_LAUNCH(VAR_DEFAULT, 3)
+                }
+            } else if (m->dict_mode == 2) {
                 if (dvar == 3) {
                     CGH_ELL_DICT_LAUNCH(3, 2)
                 } else if (dvar == 1) {
@@ -645,7 +726,10 @@ int cgh_launch_spmv_ell_halo(const cgh_matrix *m, const double *x, double *y, do
     const int grid = ell_grid_rows(rows, ell_wgs_per_cu(m));
     if (grid_out) *grid_out = grid;
 #define CGH_ELL_HALO_LAUNCH(V)                                                                                                 \
-    if (m->dict_state == 1 && m->dict_mode == 2)                                                                               \
+    if (m->dict_state == 1 && m->dict_mode == 3)                                                                               \
+        launch_r2<1, V, 3, 1>(m->K, grid, s, m->n, m->diag, m->vals_blk, m->cols8, m->off_tab, x, y, dot_partials, done, rb, re, rb2, re2, \
+                              0, *hl);                                                                                            \
+    else if (m->dict_state == 1 && m->dict_mode == 2)                                                                               \
         launch_r2<1, V, 2, 1>(m->K, grid, s, m->n, m->diag, m->vals, m->cols8, m->off_tab, x, y, dot_partials, done, rb, re, rb2, re2, \
                               0, *hl);                                                                                            \
     else if (m->dict_state == 1)                                                                                               \

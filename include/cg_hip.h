@@ -144,6 +144,11 @@ int64_t cgh_csrb_plan_host(int64_t nseg, const int *weights, int spb, int *seg_b
  * distinct (col - row) offsets (banded / stencil matrices; built on the first SpMV; CGH_ELL_DICT=0 disables).  Returns the
  * number of distinct offsets in use, 0 if the matrix does not qualify, -1 before the first SpMV / other layouts. */
 int     cgh_matrix_dict_offsets(const cgh_matrix *m);
+/* How the coded columns are laid out: 1 = one byte per entry, slot-major (rows of up to 8 slots); 2 = the codes of 4 slots
+ * of a row in one 32-bit word, slot-major; 3 = the same words AND a copy of the values "tile-blocked": the K slots of every
+ * 512-row tile lie together, so a workgroup reads one contiguous run per tile instead of K runs n*8 bytes apart (wide rows,
+ * K > 8; costs 8 more bytes of HBM per stored slot; CGH_ELL_BLOCKED=0 keeps 2).  0 = int32 columns / not built / other layouts. */
+int     cgh_matrix_dict_mode(const cgh_matrix *m);
 /* Download as slot-major full ELL of width K=cgh_matrix_width (any layout); buffers hold n*K entries. */
 int     cgh_matrix_download_ell(const cgh_matrix *m, double *ell_vals, int *ell_cols);
 int     cgh_matrix_download_diag(const cgh_matrix *m, double *diag);

@@ -165,6 +165,36 @@ def test_dictionary_coded_columns_same_bits(cga, monkeypatch, case):
         assert out["1"][1] == 0 and out["2"][1] == 0
 
 
+@pytest.mark.parametrize("generic", ["0", "1"])
+@pytest.mark.parametrize("shape", [(12, 10, 8), (16, 16, 16), (64, 9, 3), (34, 6, 5)])
+def test_tile_blocked_wide_rows_same_bits(cga, monkeypatch, shape, generic):
+    """Wide banded rows (27-point: K = 26) read tile-blocked copies of the values and of the packed code words (dict_mode 3:
+    the 26 slots of every 512-row tile together).  Same bits as the slot-major packed layout and as the reference's order,
+    for row counts that are no multiple of the tile (last tile partly empty), with the compile-time and the run-time width;
+    a strict solve (per-cell sums of p.Ap left by the SpMV where n is a multiple of 128) keeps its whole trajectory."""
+    s = foamio.poisson_coo(*shape, 0x5EED0001, 27)
+    n = s["n"]
+    rng = np.random.default_rng(11)
+    xh = rng.standard_normal(n)
+    x = cga.DeviceVector.from_host(xh); y = cga.DeviceVector(n)
+    b = cga.DeviceVector.from_host(s["source"]); sol = cga.DeviceVector(n)
+    setknob(monkeypatch, "CGH_ELL_GENERIC", generic)
+    got = {}
+    for blocked in ("0", "1"):
+        setknob(monkeypatch, "CGH_ELL_BLOCKED", blocked)
+        A = cga.Matrix.from_coo(n, s["diag"], s["upper"], s["rows"], s["cols"], cga.LAYOUT_ELL)
+        A.spmv(x, y)
+        rep, hist = cga.cg_solve(A, b, sol, max_iter=40, tol=1e-9, strict=1)
+        rep0, hist0 = cga.cg_solve(A, b, sol, max_iter=40, tol=1e-9, strict=0)
+        got[blocked] = (A.dict_mode, y.to_host(), hist, sol.to_host(), hist0)
+    assert got["0"][0] == 2 and got["1"][0] == 3
+    want = O.mv_coo(n, s["diag"], s["upper"], s["rows"], s["cols"], xh)
+    for blocked in ("0", "1"):
+        assert np.array_equal(bits(got[blocked][1]), bits(want)), blocked
+    assert same_bits_nan(got["0"][2], got["1"][2]) and same_bits_nan(got["0"][4], got["1"][4])
+    assert np.array_equal(bits(got["0"][3]), bits(got["1"][3]))
+
+
 def test_two_solvers_interleaved_reproduce_their_solo_bits(cga):
     """Nothing about a launch travels through process-wide state (cgh_spmv_opts): a strict and a throughput-mode solver on
     the SAME matrix, their iteration batches interleaved, give exactly the histories and solutions each gives alone
