@@ -337,10 +337,13 @@ def main():
                   "time of BOTH launches; HIP events around every 4th SpMV of the timed region)")
     else:
         what = "%s: 3-D %d-point Poisson %dx%dx%d, %d rows, slot-major ELL K=%d, unpreconditioned CG" % (args.workload, points, nx, ny, nz, n, A.K)
-        kernel = "spmv_ell_r2 (SpMV + p.Ap partials; %s; HIP events around every 4th launch of the timed region)" % (
+        kernel = "%s (SpMV + p.Ap partials; %s; HIP events around every 4th launch of the timed region)" % (
+            "spmv_ell_staged" if A.stage_doubles else "spmv_ell_r2",
             "1-byte dictionary-coded columns, %d offsets%s" % (
-                A.dict_offsets, "; values and code words tile-blocked: the %d slots of every 512-row tile together" % A.K
-                if A.dict_mode == 3 else "") if A.dict_offsets > 0 else "int32 columns")
+                A.dict_offsets, ("; values and code words tile-blocked: the %d slots of every 512-row tile together" % A.K
+                                 if A.dict_mode == 3 else "") +
+                ("; x gathered from %d doubles of windows staged in LDS per tile" % A.stage_doubles if A.stage_doubles else ""))
+            if A.dict_offsets > 0 else "int32 columns")
     out = {
         "metric": "CG iters/sec + SpMV achieved HBM GB/s (% of peak): value = CG iterations/s, the SpMV figures are in roofline",
         "value": args.steps / dt,

@@ -63,6 +63,7 @@ def lib():
     L.cgh_matrix_set_exact_rows.argtypes = [vp, C.c_int]
     L.cgh_matrix_dict_offsets.argtypes = [vp]
     L.cgh_matrix_dict_mode.argtypes = [vp]
+    L.cgh_matrix_stage_doubles.argtypes = [vp]
     L.cgh_config_csrb.argtypes = [C.c_int] * 6
     L.cgh_config_sell_sigma.argtypes = [C.c_int]
     L.cgh_config_persistent.argtypes = [C.c_int]
@@ -292,6 +293,7 @@ class Matrix:
 
     dict_offsets = property(lambda self: lib().cgh_matrix_dict_offsets(self.h))
     dict_mode = property(lambda self: lib().cgh_matrix_dict_mode(self.h))
+    stage_doubles = property(lambda self: lib().cgh_matrix_stage_doubles(self.h))
 
     def set_exact_rows(self, exact=True):
         check(lib().cgh_matrix_set_exact_rows(self.h, int(exact)), "set_exact_rows")

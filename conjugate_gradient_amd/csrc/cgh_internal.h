@@ -74,6 +74,9 @@ struct cgh_matrix {
     mutable int            dict_state = 0;     // 0 not tried, 1 in use, 2 not applicable
     mutable int            n_offsets = 0;
     mutable int            dict_mode = 0;      // 1: cols8 = one byte per entry (slot-major); 2: 4 slots of a row per 32-bit word; 3: the same words and the values tile-blocked (vals_blk)
+    // gathers served from LDS (spmv_ell_staged): windows of x per tile, relative to the tile's first row; 0 windows = not in use.
+    // off_tab then holds 768 ints: the offsets, and per code the LDS index of lane 0's operand for its first / second row
+    mutable int            stage_nwin = 0, stage_total = 0, stage_first[8] = {0}, stage_len[8] = {0}, stage_base[8] = {0};
     mutable double        *vals_blk = nullptr; // dict_mode 3 (wide rows): the values with the K slots of every 512-row tile together
     bool     owns = true;
     bool     exact_rows = false;  // CSR: add every row's products strictly left to right, however long the row is
@@ -120,6 +123,7 @@ struct cgh_config {
     int    ell_dict = -1;       // CGH_ELL_DICT: 0 no dictionary-coded columns, 1 / 2 force the byte / packed layout, -1 automatic
     int    ell_variant = -1;    // CGH_ELL_VARIANT: cache-hint variant of the ELL SpMV, -1 = by working-set size
     int    ell_blocked = 1;     // CGH_ELL_BLOCKED: wide dictionary-coded rows (K > 8) read tile-blocked copies of values and codes (0: slot-major)
+    int    ell_stage = 1;       // CGH_ELL_STAGE: 1 = wide dictionary-coded ELL rows (tile-blocked, K = 13 / 26) gather x from windows staged in LDS; 2 = narrow rows too; 0 = everything from L1 / L2
     int    ell_wgs = 0;         // CGH_ELL_WGS: workgroups per CU of the ELL SpMV's tile walk (0 = by kernel: 5 narrow byte-coded rows, else 8)
     double llc_mb = 224.0;      // CGH_LLC_MB: working sets below this many MiB run without streaming hints
     int    csr_window = 1024;   // CGH_CSR_WINDOW: entries per row block of the CSR stream kernel (512 | 1024 | 2048)

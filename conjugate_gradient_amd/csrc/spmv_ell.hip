@@ -224,6 +224,119 @@ __global__ __launch_bounds__(CGH_BLOCK) void spmv_ell_r2(int64_t n, int Krt, con
     }
 }
 
+// The same SpMV with the gathers served from LDS (banded matrices with dictionary-coded columns, one full row range).  A
+// tile's 512 rows read x at row + d for the matrix's few distinct offsets d: per offset one contiguous run of 512 entries,
+// and runs of neighbouring offsets overlap -- the plan (host, ell_stage_plan) merges them into at most 8 windows
+// [first, first + len) relative to the tile's first row (7-point 256^3: 512 + 1024 + 512 doubles, 16 KiB; 27-point: three
+// windows of 1028, 24 KiB).  The workgroup loads the windows with coalesced 16-byte loads -- every line once per tile,
+// where the 2 K gather instructions of a wave requested each line of x again and again from L1 / L2 -- and the lanes
+// gather from LDS.  A window is stored as its even and its odd entries apart, so the 64 lanes of one gather (rows 2 j, or
+// 2 j + 1, at one offset) read consecutive doubles: no bank conflicts.  Tables t0 / t1 give, per code, the LDS index of the
+// operand of lane 0's first / second row; lane j adds j.  Same operands, same order of operations: same bits.
+struct cgh_stage_plan {
+    int nwin = 0, total = 0;  // windows; doubles of LDS in all
+    int first[8], len[8], base[8];
+};
+
+template <int KT, int DOT, int VAR, int DICT>
+__global__ __launch_bounds__(CGH_BLOCK) void spmv_ell_staged(int64_t n, const double *__restrict__ diag, const double *__restrict__ vals,
+                                                            const void *__restrict__ cols, const int *__restrict__ stage_tab,
+                                                            const double *__restrict__ x, double *__restrict__ y,
+                                                            double *__restrict__ partials, const int *__restrict__ done, int rev,
+                                                            int64_t row_begin, int64_t row_end, cgh_stage_plan sp)
+{
+    extern __shared__ __attribute__((aligned(16))) double xs[];
+    __shared__ double lds[4];
+    __shared__ int    t0s[256], t1s[256];
+    if (done != nullptr && *done != 0) return;
+    t0s[threadIdx.x] = stage_tab[threadIdx.x];
+    t1s[threadIdx.x] = stage_tab[256 + threadIdx.x];  // (the first tile's barrier comes before anybody reads them)
+    const int64_t pair0 = row_begin >> 1, pairs = (row_end >> 1) - pair0;
+    double        local = 0.0;
+    const int64_t tiles = (pairs + CGH_BLOCK - 1) / CGH_BLOCK;
+    const int64_t tiles64 = (tiles + 63) & ~(int64_t)63;
+    constexpr bool NT = (VAR & 2) != 0, NTSTORE = (VAR & 8) != 0;
+    const bool     REMAP = (VAR & 1) != 0 && tiles > CGH_ELL_SMALL_TILES;
+    constexpr int  NW = (KT + 3) / 4;
+    for (int64_t jj = blockIdx.x; jj < tiles64; jj += gridDim.x) {
+        const int64_t j = rev ? tiles64 - 1 - jj : jj;
+        const int64_t q = j >> 3;
+        const int64_t t = REMAP ? ((q >> 3) << 6) + ((j & 7) << 3) + (q & 7) : j;
+        if (t * CGH_BLOCK >= pairs) continue;  // (the whole workgroup)
+        const int64_t pr = t * CGH_BLOCK + threadIdx.x;
+        const bool    mine = pr < pairs;
+        const int64_t i0 = (pair0 + (mine ? pr : t * CGH_BLOCK)) << 1;
+        // the tile's matrix entries first: they have the longest way
+        d2_t v[KT];
+        u2_t w[DICT >= 2 ? NW : 1];
+        unsigned short cb[DICT >= 2 ? 1 : KT];
+        if constexpr (DICT >= 2) {
+#pragma unroll
+            for (int qq = 0; qq < NW; ++qq)
+                w[qq] = stream_load<NT>(reinterpret_cast<const u2_t *>(reinterpret_cast<const unsigned *>(cols) + slot_at<DICT>(n, NW, qq, i0)));
+        } else {
+#pragma unroll
+            for (int s = 0; s < KT; ++s)
+                cb[s] = stream_load<NT>(reinterpret_cast<const unsigned short *>(cols) + (((int64_t)s * n + i0) >> 1));
+        }
+#pragma unroll
+        for (int s = 0; s < KT; ++s) v[s] = stream_load<NT>(reinterpret_cast<const d2_t *>(vals + slot_at<DICT>(n, KT, s, i0)));
+        const double2 d = *reinterpret_cast<const double2 *>(diag + i0);
+        const double2 xi = *reinterpret_cast<const double2 *>(x + i0);
+        __syncthreads();  // the previous tile's gathers are over
+        const int64_t ts = (pair0 + t * CGH_BLOCK) << 1;
+        for (int wi = 0; wi < sp.nwin; ++wi) {
+            const int     half = sp.len[wi] >> 1, base = sp.base[wi];
+            const int64_t e0 = ts + sp.first[wi];  // even
+            for (int k = threadIdx.x; k < half; k += CGH_BLOCK) {
+                const int64_t e = e0 + 2 * (int64_t)k;
+                double2       xv = make_double2(0.0, 0.0);
+                if (e >= 0 && e < n) xv = *reinterpret_cast<const double2 *>(x + e);  // (n is even: e + 1 < n as well)
+                xs[base + k] = xv.x;
+                xs[base + half + k] = xv.y;
+            }
+        }
+        __syncthreads();
+        if (!mine) continue;  // (no barrier is skipped: the next one is the next tile's first)
+        double a0 = add_rn(0.0, mul_rn(d.x, xi.x));
+        double a1 = add_rn(0.0, mul_rn(d.y, xi.y));
+#pragma unroll
+        for (int s = 0; s < KT; ++s) {
+            int c0, c1;
+            if constexpr (DICT >= 2) {
+                c0 = (w[s >> 2].x >> (8 * (s & 3))) & 0xff;
+                c1 = (w[s >> 2].y >> (8 * (s & 3))) & 0xff;
+            } else {
+                c0 = cb[s] & 0xff;
+                c1 = cb[s] >> 8;
+            }
+            const double g0 = xs[t0s[c0] + (int)threadIdx.x];
+            const double g1 = xs[t1s[c1] + (int)threadIdx.x];
+            const double p0 = madd_rn(a0, v[s].x, g0);
+            const double p1 = madd_rn(a1, v[s].y, g1);
+            a0 = c0 != 255 ? p0 : a0;
+            a1 = c1 != 255 ? p1 : a1;
+        }
+        if constexpr (NTSTORE) {
+            d2_t o;
+            o.x = a0;
+            o.y = a1;
+            __builtin_nontemporal_store(o, reinterpret_cast<d2_t *>(y + i0));
+        } else {
+            *reinterpret_cast<double2 *>(y + i0) = make_double2(a0, a1);
+        }
+        if constexpr (DOT == 1) local += xi.x * a0 + xi.y * a1;
+        if constexpr (DOT == 2) {
+            const double qsum = wave_sum_lane63(xi.x * a0 + xi.y * a1);  // (n % 128 == 0: every wave is full or idle)
+            if ((threadIdx.x & 63) == 63) partials[pr >> 6] = qsum;
+        }
+    }
+    if constexpr (DOT == 1) {
+        const double tot = block_sum_256(local, lds);
+        if (threadIdx.x == 0) partials[blockIdx.x] = tot;
+    }
+}
+
 // Any n, any alignment: one row per thread.
 template <bool DOT>
 __global__ __launch_bounds__(CGH_BLOCK) void spmv_ell_r1(int64_t n, int K, const double *__restrict__ diag,
@@ -416,6 +529,64 @@ __global__ __launch_bounds__(256) void ell_block_words(int64_t n, int NW, const 
     }
 }
 
+// largest column id stored (pads are -1): the staged kernel only serves matrices whose columns all lie below n (a
+// multi-GPU block's halo columns do not)
+__global__ __launch_bounds__(256) void ell_max_col(int64_t total, const int *__restrict__ cols, int *out)
+{
+    int m = -1;
+    for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < total; k += (int64_t)gridDim.x * 256) m = max(m, cols[k]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = max(m, __shfl_down(m, off, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(out, m);
+}
+
+constexpr int STAGE_MAX_WINDOWS = 8, STAGE_MAX_DOUBLES = 5632;  // 44 KiB of LDS per workgroup at most
+
+// Windows of x a 512-row tile needs, from the sorted offsets: [d, d + 512) per offset d, overlapping or abutting runs
+// merged; starts and lengths even (16-byte loads), each window stored as even entries then odd entries.  tab[256 + c] /
+// tab[512 + c]: LDS index of the operand of lane 0's first / second row for code c.  Returns false if the plan does not
+// fit (too many windows, too much LDS).
+bool ell_stage_plan(const std::vector<int> &offs, int count, const cgh_matrix *m, std::vector<int> &tab)
+{
+    int nwin = 0, total = 0, first[8], len[8], base[8], win_of[256];
+    for (int k = 0; k < count;) {
+        if (nwin == STAGE_MAX_WINDOWS) return false;
+        const int f = offs[k] & ~1;  // rounded down to even
+        int       last = offs[k];
+        win_of[k] = nwin;
+        int kk = k + 1;
+        while (kk < count && (int64_t)offs[kk] < (int64_t)last + 512) {
+            last = offs[kk];
+            win_of[kk] = nwin;
+            ++kk;
+        }
+        const int64_t l = ((int64_t)last - f + 512 + 1) & ~(int64_t)1;
+        if (l > STAGE_MAX_DOUBLES) return false;
+        first[nwin] = f;
+        len[nwin] = (int)l;
+        base[nwin] = total;
+        total += (int)l;
+        if (total > STAGE_MAX_DOUBLES) return false;
+        ++nwin;
+        k = kk;
+    }
+    if (nwin == 0 || total < 512) return false;
+    for (int c = 0; c < 256; ++c) tab[256 + c] = tab[512 + c] = 0;
+    for (int c = 0; c < count; ++c) {
+        const int w = win_of[c], e = offs[c] - first[w], half = len[w] >> 1;
+        tab[256 + c] = base[w] + (e & 1) * half + (e >> 1);
+        tab[512 + c] = base[w] + ((e + 1) & 1) * half + ((e + 1) >> 1);
+    }
+    m->stage_nwin = nwin;
+    m->stage_total = total;
+    for (int w = 0; w < nwin; ++w) {
+        m->stage_first[w] = first[w];
+        m->stage_len[w] = len[w];
+        m->stage_base[w] = base[w];
+    }
+    return true;
+}
+
 std::mutex g_dict_mutex;
 
 // Build m->cols8 / m->off_tab if the matrix has at most 255 distinct diagonals.  Synchronises the stream.  Called under
@@ -449,16 +620,31 @@ void ell_dict_try_build(const cgh_matrix *m, hipStream_t s)
     std::sort(offs.begin(), offs.end());
     const int count = (int)offs.size();
     offs.resize(256, 0);
+    // gathers from LDS (spmv_ell_staged): only if every column lies below n, and the windows fit
+    std::vector<int> tab(768, 0);
+    bool             staged = false;
+    if (g_cfg.ell_stage && m->n % 2 == 0) {
+        int *mx = (int *)cgh_alloc(sizeof(int));
+        int  hmx = -1;
+        if (mx && cgh_h2d(mx, &hmx, sizeof(int)) == CGH_OK) {
+            hipLaunchKernelGGL(ell_max_col, dim3(grid), dim3(256), 0, s, total, (const int *)m->cols, mx);
+            if (hipGetLastError() == hipSuccess && cgh_d2h(&hmx, mx, sizeof(int)) == CGH_OK && (int64_t)hmx < m->n)
+                staged = ell_stage_plan(offs, count, m, tab);
+        }
+        cgh_free(mx);
+    }
+    for (int k = 0; k < 256; ++k) tab[k] = offs[k];
     // narrow rows: one byte per entry, slot-major; wide rows (more load instructions than bytes are worth): 4 slots
     // of a row per 32-bit word.  CGH_ELL_DICT=1 / 2 forces a layout.
     const int mode = enabled == 2 ? 2 : (g_cfg.ell_dict == 1 ? 1 : (m->K > 8 ? 2 : 1));
     const size_t code_bytes = mode == 2 ? (size_t)((m->K + 3) / 4) * (size_t)m->n * 4 : (size_t)total;
-    m->off_tab = (int *)cgh_alloc(sizeof(int) * 256);
+    m->off_tab = (int *)cgh_alloc(sizeof(int) * 768);
     m->cols8 = (unsigned char *)cgh_alloc(code_bytes);
-    if (!m->off_tab || !m->cols8 || cgh_h2d(m->off_tab, offs.data(), sizeof(int) * 256) != CGH_OK) {
+    if (!m->off_tab || !m->cols8 || cgh_h2d(m->off_tab, tab.data(), sizeof(int) * 768) != CGH_OK) {
         cgh_ell_dict_free(m);
         return;
     }
+    if (!staged) m->stage_nwin = 0;
     if (mode == 2)
         hipLaunchKernelGGL(dict_encode_packed, dim3(grid), dim3(256), 0, s, m->n, m->K, (const int *)m->cols, (const int *)m->off_tab,
                            count, reinterpret_cast<unsigned *>(m->cols8));
@@ -522,6 +708,7 @@ void cgh_ell_dict_free(const cgh_matrix *m)
     m->cols8 = nullptr;
     m->off_tab = nullptr;
     m->vals_blk = nullptr;
+    m->stage_nwin = 0;
     if (m->dict_state == 1) m->dict_state = 2;
 }
 
@@ -545,6 +732,23 @@ bool cgh_fits_llc(const cgh_matrix *m, double times)
     return (double)m->stored * per_entry + (double)m->n * 8.0 * 5.0 <= limit * times;
 }
 
+// Does the kernel that gathers from LDS (spmv_ell_staged) serve this matrix's full-range launches?  0 no; 1 narrow rows with
+// byte codes (only on request, CGH_ELL_STAGE=2: the 7-point kernel gains nothing -- 0.203 against 0.200 ms stand-alone at
+// 256^3, 385 against 375 us per CG iteration -- its 12 gathers per row pair are served by L1 / L2 as fast as the staging
+// costs; the 27-point kernel's 52 are not); 2 wide rows with tile-blocked code words (K = 13 / 26).
+static int ell_staged_kind(const cgh_matrix *m)
+{
+    if (m->dict_state != 1 || m->stage_nwin <= 0 || !g_cfg.ell_stage || g_cfg.ell_generic) return 0;
+    if (g_cfg.ell_stage >= 2 && m->dict_mode == 1 && m->K >= 1 && m->K <= 8) return 1;
+    return m->dict_mode == 3 && (m->K == 13 || m->K == 26) ? 2 : 0;
+}
+
+extern "C" int cgh_matrix_stage_doubles(const cgh_matrix *m)
+{
+    if (!m || m->layout != CGH_LAYOUT_ELL || __atomic_load_n(&m->dict_state, __ATOMIC_ACQUIRE) != 1) return 0;
+    return ell_staged_kind(m) ? m->stage_total : 0;
+}
+
 // Workgroups per CU of the tile walk.  Narrow rows with byte-coded columns (the 7-point kernel: 64 VGPRs, so eight
 // workgroups per CU would be resident) run fastest with FIVE per CU -- measured in round 3 at 256^3, us per CG iteration:
 // 2048 workgroups 400.3, 1536 388.5, 1280 373.4, 1024 378.9, 768 396.6, 512 460 (grids that are no multiple of the CU count
@@ -553,6 +757,9 @@ bool cgh_fits_llc(const cgh_matrix *m, double times)
 static int ell_wgs_per_cu(const cgh_matrix *m)
 {
     if (g_cfg.ell_wgs > 0) return g_cfg.ell_wgs;
+    // wide rows with the gathers staged in LDS (153 VGPRs at K = 26: three workgroups per CU are resident): one round of
+    // resident workgroups -- 27-point 256^3: 0.716 ms with three per CU, 0.732 with two, 0.741 with eight, 0.866 with four
+    if (m != nullptr && ell_staged_kind(m) == 2) return 3;
     return m != nullptr && m->dict_state == 1 && m->dict_mode == 1 && m->K <= 8 ? 5 : 8;
 }
 
@@ -567,6 +774,53 @@ static int ell_grid_rows(int64_t rows, int per_cu)
 }
 
 int cgh_ell_grid(const cgh_matrix *m) { return ell_grid_rows(m->n, ell_wgs_per_cu(m)); }
+
+// The staged kernel serves: a dictionary-coded matrix with a plan, byte codes (narrow rows, K <= 8) or tile-blocked words
+// (K = 13 / 26), one row range.  Returns false if this launch is not one of those (the caller goes on with spmv_ell_r2).
+template <int DOT>
+static bool launch_staged(const cgh_matrix *m, int var, int grid, hipStream_t s, const double *x, double *y, double *partials,
+                          const int *done, int rev, int64_t rb, int64_t re)
+{
+    const int  kind = ell_staged_kind(m);
+    const bool narrow = kind == 1, wide = kind == 2;
+    if (!kind) return false;
+    cgh_stage_plan sp;
+    sp.nwin = m->stage_nwin;
+    sp.total = m->stage_total;
+    for (int w = 0; w < 8; ++w) {
+        sp.first[w] = m->stage_first[w];
+        sp.len[w] = m->stage_len[w];
+        sp.base[w] = m->stage_base[w];
+    }
+    const size_t  shm = sizeof(double) * (size_t)sp.total;
+    const double *vals = wide ? m->vals_blk : m->vals;
+#define CGH_STAGED_CASE(KK, V, MODE)                                                                                             \
+    case KK:                                                                                                                     \
+        hipLaunchKernelGGL((spmv_ell_staged<KK, DOT, V, MODE>), dim3(grid), dim3(CGH_BLOCK), shm, s, m->n, (const double *)m->diag, vals, \
+                           (const void *)m->cols8, (const int *)m->off_tab + 256, x, y, partials, done, rev, rb, re, sp);        \
+        break;
+#define CGH_STAGED_VAR(V)                                                                                                        \
+    if (narrow) {                                                                                                                \
+        switch (m->K) {                                                                                                          \
+            CGH_STAGED_CASE(1, V, 1) CGH_STAGED_CASE(2, V, 1) CGH_STAGED_CASE(3, V, 1) CGH_STAGED_CASE(4, V, 1)                  \
+            CGH_STAGED_CASE(5, V, 1) CGH_STAGED_CASE(6, V, 1) CGH_STAGED_CASE(7, V, 1) CGH_STAGED_CASE(8, V, 1)                  \
+        }                                                                                                                        \
+    } else {                                                                                                                     \
+        switch (m->K) {                                                                                                          \
+            CGH_STAGED_CASE(13, V, 3) CGH_STAGED_CASE(26, V, 3)                                                                  \
+        }                                                                                                                        \
+    }
+    if (var == 1) {
+        CGH_STAGED_VAR(1)
+    } else if (var == 3) {
+        CGH_STAGED_VAR(3)
+    } else {
+        CGH_STAGED_VAR(VAR_DEFAULT)
+    }
+#undef CGH_STAGED_VAR
+#undef CGH_STAGED_CASE
+    return true;
+}
 
 // y[rb:re) = (A x)[rb:re).  The slot stride is m->n; x may be longer than n (multi-GPU: halo entries follow the owned ones).
 int cgh_launch_spmv_ell_range(const cgh_matrix *m, const double *x, double *y, double *dot_partials, int *grid_out,
@@ -619,7 +873,8 @@ int cgh_launch_spmv_ell_range2(const cgh_matrix *m, const double *x, double *y, 
     if (ell_vector_path(m, x, y) && rb % 2 == 0 && re % 2 == 0 && rb2 % 2 == 0 && re2 % 2 == 0) {
         // strict mode's per-cell sums of x.y instead of per-workgroup partials
         if (cell_sums != nullptr && dot_partials == nullptr && rb == 0 && re == m->n && re2 <= rb2 && m->n % 128 == 0) {
-            if (m->dict_state == 1 && m->dict_mode == 3)
+            if (launch_staged<2>(m, VAR_DEFAULT, grid, s, x, y, cell_sums, done, rev, rb, re)) {
+            } else if (m->dict_state == 1 && m->dict_mode == 3)
                 launch_r2<2, VAR_DEFAULT, 3>(m->K, grid, s, m->n, m->diag, m->vals_blk, m->cols8, m->off_tab, x, y, cell_sums, done,
                                              rb, re, rb2, re2, rev);
             else if (m->dict_state == 1 && m->dict_mode == 2)
@@ -641,6 +896,11 @@ int cgh_launch_spmv_ell_range2(const cgh_matrix *m, const double *x, double *y, 
             // hints cost 4-8 % of an iteration: tools/quick_mall.py); CGH_ELL_VARIANT=1|3|11 overrides (3: NT loads only)
             const int forced = g_cfg.ell_variant;
             const int dvar = (forced == 1 || forced == 3 || forced == 11) ? forced : (cgh_fits_llc(m, 1.0) ? 1 : VAR_DEFAULT);
+            if (re2 <= rb2 && (dot_partials ? launch_staged<1>(m, dvar, grid, s, x, y, dot_partials, done, rev, rb, re)
+                                            : launch_staged<0>(m, dvar, grid, s, x, y, nullptr, done, rev, rb, re))) {
+                CGH_HIP(hipGetLastError());
+                return CGH_OK;
+            }
 #define CGH_ELL_DICT_LAUNCH(V, MODE)                                                                                       \
     if (dot_partials)                                                                                                      \
         launch_r2<true, V, MODE>(m->K, grid, s, m->n, m->diag, MODE == 3 ? m->vals_blk : m->vals, m->cols8, m->off_tab, x, y,  \

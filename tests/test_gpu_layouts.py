@@ -180,19 +180,48 @@ def test_tile_blocked_wide_rows_same_bits(cga, monkeypatch, shape, generic):
     b = cga.DeviceVector.from_host(s["source"]); sol = cga.DeviceVector(n)
     setknob(monkeypatch, "CGH_ELL_GENERIC", generic)
     got = {}
-    for blocked in ("0", "1"):
+    for blocked, stage in (("0", "1"), ("1", "0"), ("1", "1")):
         setknob(monkeypatch, "CGH_ELL_BLOCKED", blocked)
+        setknob(monkeypatch, "CGH_ELL_STAGE", stage)
         A = cga.Matrix.from_coo(n, s["diag"], s["upper"], s["rows"], s["cols"], cga.LAYOUT_ELL)
         A.spmv(x, y)
         rep, hist = cga.cg_solve(A, b, sol, max_iter=40, tol=1e-9, strict=1)
         rep0, hist0 = cga.cg_solve(A, b, sol, max_iter=40, tol=1e-9, strict=0)
-        got[blocked] = (A.dict_mode, y.to_host(), hist, sol.to_host(), hist0)
-    assert got["0"][0] == 2 and got["1"][0] == 3
+        got[blocked + stage] = (A.dict_mode, y.to_host(), hist, sol.to_host(), hist0, A.stage_doubles)
+    assert got["01"][0] == 2 and got["10"][0] == 3 and got["11"][0] == 3
+    # gathers from LDS: the tile-blocked layout with a compile-time width only (three windows of x per tile here)
+    assert got["01"][5] == 0 and got["10"][5] == 0 and (got["11"][5] > 0) == (generic == "0")
     want = O.mv_coo(n, s["diag"], s["upper"], s["rows"], s["cols"], xh)
-    for blocked in ("0", "1"):
-        assert np.array_equal(bits(got[blocked][1]), bits(want)), blocked
-    assert same_bits_nan(got["0"][2], got["1"][2]) and same_bits_nan(got["0"][4], got["1"][4])
-    assert np.array_equal(bits(got["0"][3]), bits(got["1"][3]))
+    for k in got:
+        assert np.array_equal(bits(got[k][1]), bits(want)), k
+        assert same_bits_nan(got["01"][2], got[k][2]) and same_bits_nan(got["01"][4], got[k][4]), k
+        assert np.array_equal(bits(got["01"][3]), bits(got[k][3])), k
+
+
+@pytest.mark.parametrize("shape,points", [((20, 14, 10), 7), ((64, 8, 4), 7), ((16, 16, 16), 7), ((130, 3, 2), 7)])
+def test_narrow_rows_gathering_from_lds_same_bits(cga, monkeypatch, shape, points):
+    """CGH_ELL_STAGE=2: the kernel that stages x in LDS also serves narrow byte-coded rows (off by default: no gain there).
+    Same bits as the gathers from L1 / L2 -- SpMV with non-finite entries in x, and a strict and a throughput-mode solve."""
+    s = foamio.poisson_coo(*shape, 0x5EED0001, points)
+    n = s["n"]
+    rng = np.random.default_rng(12)
+    xh = rng.standard_normal(n)
+    xh[rng.integers(0, n, 3)] = [np.inf, -np.inf, np.nan]
+    x = cga.DeviceVector.from_host(xh); y = cga.DeviceVector(n)
+    b = cga.DeviceVector.from_host(s["source"]); sol = cga.DeviceVector(n)
+    got = {}
+    for stage in ("1", "2"):
+        setknob(monkeypatch, "CGH_ELL_STAGE", stage)
+        A = cga.Matrix.from_coo(n, s["diag"], s["upper"], s["rows"], s["cols"], cga.LAYOUT_ELL)
+        A.spmv(x, y)
+        rep, hist = cga.cg_solve(A, b, sol, max_iter=30, tol=1e-9, strict=1)
+        xs = sol.to_host()
+        rep0, hist0 = cga.cg_solve(A, b, sol, max_iter=30, tol=1e-9, strict=0)
+        got[stage] = (A.stage_doubles, y.to_host(), hist, xs, hist0)
+    assert got["1"][0] == 0 and got["2"][0] >= 512
+    assert same_bits_nan(got["1"][1], got["2"][1])
+    assert same_bits_nan(got["1"][2], got["2"][2]) and same_bits_nan(got["1"][4], got["2"][4])
+    assert np.array_equal(bits(got["1"][3]), bits(got["2"][3]))
 
 
 def test_two_solvers_interleaved_reproduce_their_solo_bits(cga):

@@ -1,7 +1,7 @@
 """profiles/<round>_traffic_<name>.json from the two rocprofv3 --pmc passes of tools/pmc_bench.sh (FETCH_SIZE, WRITE_SIZE).
     python tools/pmc_traffic.py <workload> <name> <dir with FETCH_SIZE/ and WRITE_SIZE/> <round>
-The SpMV of the timed loop is the spmv_ell_r2<K, 1, ...> (per-workgroup p.Ap partials, no halo) instantiation with the most
-launches; pl_8m: pb_expand + pb_accumulate.  Corrections as /opt/skills/guides/MI355X_MICROARCH.md prescribes: units are KiB;
+The SpMV of the timed loop is the spmv_ell_r2<K, 1, ...> / spmv_ell_staged<K, 1, ...> (per-workgroup p.Ap partials, no halo)
+instantiation with the most launches; pl_8m: pb_expand + pb_accumulate.  Corrections as /opt/skills/guides/MI355X_MICROARCH.md prescribes: units are KiB;
 FETCH_SIZE on gfx950 counts 64 bytes per 128-byte request -- the factor is CALIBRATED here on the 1 GiB read16 / copy16 launches
 of the same run (bench.py's ceilings), not assumed; WRITE_SIZE is calibrated on copy16's 1 GiB of stores."""
 import collections
@@ -35,7 +35,7 @@ if workload.startswith("pl_"):
     # one SpMV = pb_expand + pb_accumulate; of the latter the instantiation of the timed loop (with p.Ap: the most launches)
     ks = [k for k in F if k.startswith("pb_expand")] + [max((k for k in F if k.startswith("pb_accumulate")), key=lambda k: F[k][1])]
 else:
-    cand = [k for k in F if re.match(r"spmv_ell_r2<\d+, 1, \d+, \d+, 0>", k)]
+    cand = [k for k in F if re.match(r"spmv_ell_r2<\d+, 1, \d+, \d+, 0>", k) or re.match(r"spmv_ell_staged<\d+, 1, \d+, \d+>", k)]
     ks = [max(cand, key=lambda k: F[k][1])]
 by = {}
 total = 0.0
