@@ -77,6 +77,7 @@ struct cgh_matrix {
     // gathers served from LDS (spmv_ell_staged): windows of x per tile, relative to the tile's first row; 0 windows = not in use.
     // off_tab then holds 768 ints: the offsets, and per code the LDS index of lane 0's operand for its first / second row
     mutable int            stage_nwin = 0, stage_total = 0, stage_first[8] = {0}, stage_len[8] = {0}, stage_base[8] = {0};
+    mutable bool           stage_any_row = false;  // every column lies below n: any row range may be staged (else only interior rows)
     mutable double        *vals_blk = nullptr; // dict_mode 3 (wide rows): the values with the K slots of every 512-row tile together
     bool     owns = true;
     bool     exact_rows = false;  // CSR: add every row's products strictly left to right, however long the row is
@@ -115,6 +116,8 @@ struct cgh_spmv_opts {
     bool   *cell_sums_written = nullptr; // binade prediction); *cell_sums_written says whether the kernel it chose did
     int     reverse = 0;                 // 1: walk the rows from the end (serpentine sweeps)
     bool    no_alloc = false;            // the call must not allocate: an ELL matrix's column dictionary is not built now
+    bool    interior_rows = false;       // the rows of this launch hold no column >= n (the interior of a multi-GPU block, whose
+                                         // other rows read halo entries behind x's n owned ones): the LDS-staged kernel may serve them
 };
 
 // Knobs read from the environment ONCE, in cgh_init (never in a launch path); cgh_config_* setters override them.

@@ -310,7 +310,9 @@ int spmv_ranges(cgh_dist *d, bool interior, bool boundary, bool with_dot, int *c
     const int64_t a = d->int_begin, b = d->int_end, nl = d->n_loc;
     int           g = 0, rc;
     if (interior) {
-        rc = cgh_launch_spmv_ell_range(&d->mat, d->p, d->Ap, with_dot ? d->partA + *count_io : nullptr, &g, done, s, a, b);
+        cgh_spmv_opts so;
+        so.interior_rows = true;  // rows [a, b) read no halo entry: wide rows may gather from LDS (spmv_ell_staged)
+        rc = cgh_launch_spmv_ell_range(&d->mat, d->p, d->Ap, with_dot ? d->partA + *count_io : nullptr, &g, done, s, a, b, &so);
         if (rc) return rc;
         *count_io += g;
     }

@@ -628,8 +628,12 @@ void ell_dict_try_build(const cgh_matrix *m, hipStream_t s)
         int  hmx = -1;
         if (mx && cgh_h2d(mx, &hmx, sizeof(int)) == CGH_OK) {
             hipLaunchKernelGGL(ell_max_col, dim3(grid), dim3(256), 0, s, total, (const int *)m->cols, mx);
-            if (hipGetLastError() == hipSuccess && cgh_d2h(&hmx, mx, sizeof(int)) == CGH_OK && (int64_t)hmx < m->n)
+            if (hipGetLastError() == hipSuccess && cgh_d2h(&hmx, mx, sizeof(int)) == CGH_OK) {
+                // columns at or beyond n (the halo entries of a multi-GPU block) are never staged (the windows end at n): such a
+                // matrix is served for launches over its interior rows only (cgh_spmv_opts::interior_rows)
                 staged = ell_stage_plan(offs, count, m, tab);
+                m->stage_any_row = (int64_t)hmx < m->n;
+            }
         }
         cgh_free(mx);
     }
@@ -736,9 +740,10 @@ bool cgh_fits_llc(const cgh_matrix *m, double times)
 // byte codes (only on request, CGH_ELL_STAGE=2: the 7-point kernel gains nothing -- 0.203 against 0.200 ms stand-alone at
 // 256^3, 385 against 375 us per CG iteration -- its 12 gathers per row pair are served by L1 / L2 as fast as the staging
 // costs; the 27-point kernel's 52 are not); 2 wide rows with tile-blocked code words (K = 13 / 26).
-static int ell_staged_kind(const cgh_matrix *m)
+static int ell_staged_kind(const cgh_matrix *m, bool interior_rows = false)
 {
     if (m->dict_state != 1 || m->stage_nwin <= 0 || !g_cfg.ell_stage || g_cfg.ell_generic) return 0;
+    if (!m->stage_any_row && !interior_rows) return 0;
     if (g_cfg.ell_stage >= 2 && m->dict_mode == 1 && m->K >= 1 && m->K <= 8) return 1;
     return m->dict_mode == 3 && (m->K == 13 || m->K == 26) ? 2 : 0;
 }
@@ -754,12 +759,12 @@ extern "C" int cgh_matrix_stage_doubles(const cgh_matrix *m)
 // 2048 workgroups 400.3, 1536 388.5, 1280 373.4, 1024 378.9, 768 396.6, 512 460 (grids that are no multiple of the CU count
 // lose: 1152 393, 1408 411); 4.2M rows 101.9 -> 98.4, 8.4M 194.8 -> 189.8.  Wide rows (27-point, 220 VGPRs: two workgroups per
 // CU resident whatever the grid) and int32 columns keep eight (0.845 vs 0.854 ms; 445.5 vs 450.1 us).  CGH_ELL_WGS overrides.
-static int ell_wgs_per_cu(const cgh_matrix *m)
+static int ell_wgs_per_cu(const cgh_matrix *m, bool interior_rows = false)
 {
     if (g_cfg.ell_wgs > 0) return g_cfg.ell_wgs;
     // wide rows with the gathers staged in LDS (153 VGPRs at K = 26: three workgroups per CU are resident): one round of
     // resident workgroups -- 27-point 256^3: 0.716 ms with three per CU, 0.732 with two, 0.741 with eight, 0.866 with four
-    if (m != nullptr && ell_staged_kind(m) == 2) return 3;
+    if (m != nullptr && ell_staged_kind(m, interior_rows) == 2) return 3;
     return m != nullptr && m->dict_state == 1 && m->dict_mode == 1 && m->K <= 8 ? 5 : 8;
 }
 
@@ -779,9 +784,9 @@ int cgh_ell_grid(const cgh_matrix *m) { return ell_grid_rows(m->n, ell_wgs_per_c
 // (K = 13 / 26), one row range.  Returns false if this launch is not one of those (the caller goes on with spmv_ell_r2).
 template <int DOT>
 static bool launch_staged(const cgh_matrix *m, int var, int grid, hipStream_t s, const double *x, double *y, double *partials,
-                          const int *done, int rev, int64_t rb, int64_t re)
+                          const int *done, int rev, int64_t rb, int64_t re, bool interior_rows)
 {
-    const int  kind = ell_staged_kind(m);
+    const int  kind = ell_staged_kind(m, interior_rows);
     const bool narrow = kind == 1, wide = kind == 2;
     if (!kind) return false;
     cgh_stage_plan sp;
@@ -859,7 +864,8 @@ int cgh_launch_spmv_ell_range2(const cgh_matrix *m, const double *x, double *y, 
             if (m->dict_state == 0) ell_dict_try_build(m, s);
         }
     }
-    const int grid = ell_grid_rows(rows, vector_path ? ell_wgs_per_cu(m) : 8);
+    const bool interior = opts && opts->interior_rows && re2 <= rb2;
+    const int  grid = ell_grid_rows(rows, vector_path ? ell_wgs_per_cu(m, interior) : 8);
     if (grid_out) *grid_out = grid;
     if (!(ell_vector_path(m, x, y) && rb % 2 == 0 && re % 2 == 0 && rb2 % 2 == 0 && re2 % 2 == 0) && re2 > rb2) {
         // scalar path: one launch per range
@@ -873,7 +879,7 @@ int cgh_launch_spmv_ell_range2(const cgh_matrix *m, const double *x, double *y, 
     if (ell_vector_path(m, x, y) && rb % 2 == 0 && re % 2 == 0 && rb2 % 2 == 0 && re2 % 2 == 0) {
         // strict mode's per-cell sums of x.y instead of per-workgroup partials
         if (cell_sums != nullptr && dot_partials == nullptr && rb == 0 && re == m->n && re2 <= rb2 && m->n % 128 == 0) {
-            if (launch_staged<2>(m, VAR_DEFAULT, grid, s, x, y, cell_sums, done, rev, rb, re)) {
+            if (launch_staged<2>(m, VAR_DEFAULT, grid, s, x, y, cell_sums, done, rev, rb, re, interior)) {
             } else if (m->dict_state == 1 && m->dict_mode == 3)
                 launch_r2<2, VAR_DEFAULT, 3>(m->K, grid, s, m->n, m->diag, m->vals_blk, m->cols8, m->off_tab, x, y, cell_sums, done,
                                              rb, re, rb2, re2, rev);
@@ -896,8 +902,8 @@ int cgh_launch_spmv_ell_range2(const cgh_matrix *m, const double *x, double *y, 
             // hints cost 4-8 % of an iteration: tools/quick_mall.py); CGH_ELL_VARIANT=1|3|11 overrides (3: NT loads only)
             const int forced = g_cfg.ell_variant;
             const int dvar = (forced == 1 || forced == 3 || forced == 11) ? forced : (cgh_fits_llc(m, 1.0) ? 1 : VAR_DEFAULT);
-            if (re2 <= rb2 && (dot_partials ? launch_staged<1>(m, dvar, grid, s, x, y, dot_partials, done, rev, rb, re)
-                                            : launch_staged<0>(m, dvar, grid, s, x, y, nullptr, done, rev, rb, re))) {
+            if (re2 <= rb2 && (dot_partials ? launch_staged<1>(m, dvar, grid, s, x, y, dot_partials, done, rev, rb, re, interior)
+                                            : launch_staged<0>(m, dvar, grid, s, x, y, nullptr, done, rev, rb, re, interior))) {
                 CGH_HIP(hipGetLastError());
                 return CGH_OK;
             }
