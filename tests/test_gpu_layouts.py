@@ -198,6 +198,45 @@ def test_tile_blocked_wide_rows_same_bits(cga, monkeypatch, shape, generic):
         assert np.array_equal(bits(got["01"][3]), bits(got[k][3])), k
 
 
+@pytest.mark.parametrize("K,n,spread", [(13, 3000, 40), (26, 2050, 900), (13, 1538, 8), (26, 5120, 5000)])
+def test_general_banded_ell_of_compile_time_wide_widths(cga, monkeypatch, K, n, spread):
+    """Any banded ELL matrix of a wide compile-time width (13, 26 slots; not symmetric, pads in the middle of rows, offsets far
+    apart so that the staging plan has several windows or -- last case -- does not fit and the gathers stay with L1 / L2):
+    every variant (slot-major packed codes, tile-blocked, tile-blocked + LDS-staged) adds each row's products in slot
+    order, bit for bit as a plain loop does."""
+    rng = np.random.default_rng(K * 1000 + n)
+    offs = np.unique(np.concatenate([rng.integers(-spread, spread + 1, 3 * K), [-1, 1]]))
+    offs = rng.permutation(offs[offs != 0])[:K]
+    assert offs.size == K
+    i = np.arange(n)
+    ec = np.full((K, n), -1, dtype=np.int32)
+    ev = np.zeros((K, n))
+    for s_ in range(K):
+        c = i + offs[s_]
+        ok = (c >= 0) & (c < n) & (rng.random(n) < 0.9)      # pads wherever the column falls outside, and at random
+        ec[s_, ok] = c[ok]
+        ev[s_, ok] = rng.standard_normal(int(ok.sum()))
+    diag = rng.standard_normal(n) + 4.0
+    xh = rng.standard_normal(n)
+    want = 0.0 + diag * xh
+    for s_ in range(K):
+        ok = ec[s_] >= 0
+        t = want + ev[s_] * xh[np.where(ok, ec[s_], 0)]
+        want = np.where(ok, t, want)
+    x = cga.DeviceVector.from_host(xh); y = cga.DeviceVector(n)
+    staged = {}
+    for blocked, stage in (("0", "0"), ("1", "0"), ("1", "1")):
+        setknob(monkeypatch, "CGH_ELL_BLOCKED", blocked)
+        setknob(monkeypatch, "CGH_ELL_STAGE", stage)
+        A = cga.Matrix.from_ell(n, K, diag, ev.ravel(), ec.ravel())
+        A.spmv(x, y)
+        assert A.dict_mode == (3 if blocked == "1" else 2)
+        assert np.array_equal(bits(y.to_host()), bits(want)), (blocked, stage)
+        staged[blocked + stage] = A.stage_doubles
+    assert staged["00"] == 0 and staged["10"] == 0
+    assert (staged["11"] > 0) == (spread < 5000)
+
+
 @pytest.mark.parametrize("shape,points", [((20, 14, 10), 7), ((64, 8, 4), 7), ((16, 16, 16), 7), ((130, 3, 2), 7)])
 def test_narrow_rows_gathering_from_lds_same_bits(cga, monkeypatch, shape, points):
     """CGH_ELL_STAGE=2: the kernel that stages x in LDS also serves narrow byte-coded rows (off by default: no gain there).
