@@ -239,7 +239,7 @@ struct cgh_stage_plan {
 };
 
 template <int KT, int DOT, int VAR, int DICT>
-__global__ __launch_bounds__(CGH_BLOCK) void spmv_ell_staged(int64_t n, const double *__restrict__ diag, const double *__restrict__ vals,
+__global__ __launch_bounds__(CGH_BLOCK) void spmv_ell_staged(int64_t n, int Krt, const double *__restrict__ diag, const double *__restrict__ vals,
                                                             const void *__restrict__ cols, const int *__restrict__ stage_tab,
                                                             const double *__restrict__ x, double *__restrict__ y,
                                                             double *__restrict__ partials, const int *__restrict__ done, int rev,
@@ -258,6 +258,8 @@ __global__ __launch_bounds__(CGH_BLOCK) void spmv_ell_staged(int64_t n, const do
     constexpr bool NT = (VAR & 2) != 0, NTSTORE = (VAR & 8) != 0;
     const bool     REMAP = (VAR & 1) != 0 && tiles > CGH_ELL_SMALL_TILES;
     constexpr int  NW = (KT + 3) / 4;
+    constexpr int  KA = KT > 0 ? KT : 1;  // (array sizes of the compile-time path)
+    const int      K = KT > 0 ? KT : Krt;
     for (int64_t jj = blockIdx.x; jj < tiles64; jj += gridDim.x) {
         const int64_t j = rev ? tiles64 - 1 - jj : jj;
         const int64_t q = j >> 3;
@@ -266,10 +268,70 @@ __global__ __launch_bounds__(CGH_BLOCK) void spmv_ell_staged(int64_t n, const do
         const int64_t pr = t * CGH_BLOCK + threadIdx.x;
         const bool    mine = pr < pairs;
         const int64_t i0 = (pair0 + (mine ? pr : t * CGH_BLOCK)) << 1;
+        if constexpr (KT == 0) {
+            // any width (run-time K): the windows first, then slot after slot -- codes, value, two gathers from LDS
+            const double2 d = *reinterpret_cast<const double2 *>(diag + i0);
+            const double2 xi = *reinterpret_cast<const double2 *>(x + i0);
+            __syncthreads();  // the previous tile's gathers are over
+            const int64_t ts = (pair0 + t * CGH_BLOCK) << 1;
+            for (int wi = 0; wi < sp.nwin; ++wi) {
+                const int     half = sp.len[wi] >> 1, base = sp.base[wi];
+                const int64_t e0 = ts + sp.first[wi];
+                for (int k = threadIdx.x; k < half; k += CGH_BLOCK) {
+                    const int64_t e = e0 + 2 * (int64_t)k;
+                    double2       xv = make_double2(0.0, 0.0);
+                    if (e >= 0 && e < n) xv = *reinterpret_cast<const double2 *>(x + e);
+                    xs[base + k] = xv.x;
+                    xs[base + half + k] = xv.y;
+                }
+            }
+            __syncthreads();
+            if (!mine) continue;
+            double a0 = add_rn(0.0, mul_rn(d.x, xi.x));
+            double a1 = add_rn(0.0, mul_rn(d.y, xi.y));
+            const int nw = (K + 3) / 4;
+            u2_t      w;
+            w.x = w.y = 0;
+#pragma unroll 4
+            for (int s = 0; s < K; ++s) {
+                int c0, c1;
+                if constexpr (DICT >= 2) {
+                    if ((s & 3) == 0)
+                        w = stream_load<NT>(reinterpret_cast<const u2_t *>(reinterpret_cast<const unsigned *>(cols) + slot_at<DICT>(n, nw, s >> 2, i0)));
+                    c0 = (w.x >> (8 * (s & 3))) & 0xff;
+                    c1 = (w.y >> (8 * (s & 3))) & 0xff;
+                } else {
+                    const unsigned short cc = stream_load<NT>(reinterpret_cast<const unsigned short *>(cols) + (((int64_t)s * n + i0) >> 1));
+                    c0 = cc & 0xff;
+                    c1 = cc >> 8;
+                }
+                const d2_t   v = stream_load<NT>(reinterpret_cast<const d2_t *>(vals + slot_at<DICT>(n, K, s, i0)));
+                const double g0 = xs[t0s[c0] + (int)threadIdx.x];
+                const double g1 = xs[t1s[c1] + (int)threadIdx.x];
+                const double p0 = madd_rn(a0, v.x, g0);
+                const double p1 = madd_rn(a1, v.y, g1);
+                a0 = c0 != 255 ? p0 : a0;
+                a1 = c1 != 255 ? p1 : a1;
+            }
+            if constexpr (NTSTORE) {
+                d2_t o;
+                o.x = a0;
+                o.y = a1;
+                __builtin_nontemporal_store(o, reinterpret_cast<d2_t *>(y + i0));
+            } else {
+                *reinterpret_cast<double2 *>(y + i0) = make_double2(a0, a1);
+            }
+            if constexpr (DOT == 1) local += xi.x * a0 + xi.y * a1;
+            if constexpr (DOT == 2) {
+                const double qsum = wave_sum_lane63(xi.x * a0 + xi.y * a1);
+                if ((threadIdx.x & 63) == 63) partials[pr >> 6] = qsum;
+            }
+            continue;
+        }
         // the tile's matrix entries first: they have the longest way
-        d2_t v[KT];
-        u2_t w[DICT >= 2 ? NW : 1];
-        unsigned short cb[DICT >= 2 ? 1 : KT];
+        d2_t v[KA];
+        u2_t w[DICT >= 2 ? (NW > 0 ? NW : 1) : 1];
+        unsigned short cb[DICT >= 2 ? 1 : KA];
         if constexpr (DICT >= 2) {
 #pragma unroll
             for (int qq = 0; qq < NW; ++qq)
@@ -742,10 +804,10 @@ bool cgh_fits_llc(const cgh_matrix *m, double times)
 // costs; the 27-point kernel's 52 are not); 2 wide rows with tile-blocked code words (K = 13 / 26).
 static int ell_staged_kind(const cgh_matrix *m, bool interior_rows = false)
 {
-    if (m->dict_state != 1 || m->stage_nwin <= 0 || !g_cfg.ell_stage || g_cfg.ell_generic) return 0;
+    if (m->dict_state != 1 || m->stage_nwin <= 0 || !g_cfg.ell_stage) return 0;
     if (!m->stage_any_row && !interior_rows) return 0;
     if (g_cfg.ell_stage >= 2 && m->dict_mode == 1 && m->K >= 1 && m->K <= 8) return 1;
-    return m->dict_mode == 3 && (m->K == 13 || m->K == 26) ? 2 : 0;
+    return m->dict_mode == 3 && m->K > 8 ? 2 : 0;  // (13 and 26 slots at compile time, any other width with a run-time K)
 }
 
 extern "C" int cgh_matrix_stage_doubles(const cgh_matrix *m)
@@ -764,7 +826,13 @@ static int ell_wgs_per_cu(const cgh_matrix *m, bool interior_rows = false)
     if (g_cfg.ell_wgs > 0) return g_cfg.ell_wgs;
     // wide rows with the gathers staged in LDS (153 VGPRs at K = 26: three workgroups per CU are resident): one round of
     // resident workgroups -- 27-point 256^3: 0.716 ms with three per CU, 0.732 with two, 0.741 with eight, 0.866 with four
-    if (m != nullptr && ell_staged_kind(m, interior_rows) == 2) return 3;
+    if (m != nullptr && ell_staged_kind(m, interior_rows) == 2) {
+        if (!g_cfg.ell_generic && (m->K == 13 || m->K == 26)) return 3;
+        // the run-time-width kernel is lean in registers: five per CU (27-point 256^3 through it: 0.731 ms; three 0.750, eight
+        // 0.781) -- or as many as the staged windows leave room for in the CU's 160 KiB of LDS
+        const int fit = (int)((150 * 1024) / (sizeof(double) * (size_t)m->stage_total + 2200));
+        return fit >= 5 ? 5 : (fit < 1 ? 1 : fit);
+    }
     return m != nullptr && m->dict_state == 1 && m->dict_mode == 1 && m->K <= 8 ? 5 : 8;
 }
 
@@ -801,18 +869,22 @@ static bool launch_staged(const cgh_matrix *m, int var, int grid, hipStream_t s,
     const double *vals = wide ? m->vals_blk : m->vals;
 #define CGH_STAGED_CASE(KK, V, MODE)                                                                                             \
     case KK:                                                                                                                     \
-        hipLaunchKernelGGL((spmv_ell_staged<KK, DOT, V, MODE>), dim3(grid), dim3(CGH_BLOCK), shm, s, m->n, (const double *)m->diag, vals, \
+        hipLaunchKernelGGL((spmv_ell_staged<KK, DOT, V, MODE>), dim3(grid), dim3(CGH_BLOCK), shm, s, m->n, m->K, (const double *)m->diag, vals, \
                            (const void *)m->cols8, (const int *)m->off_tab + 256, x, y, partials, done, rev, rb, re, sp);        \
         break;
 #define CGH_STAGED_VAR(V)                                                                                                        \
     if (narrow) {                                                                                                                \
-        switch (m->K) {                                                                                                          \
+        switch (g_cfg.ell_generic ? 0 : m->K) {                                                                                  \
             CGH_STAGED_CASE(1, V, 1) CGH_STAGED_CASE(2, V, 1) CGH_STAGED_CASE(3, V, 1) CGH_STAGED_CASE(4, V, 1)                  \
             CGH_STAGED_CASE(5, V, 1) CGH_STAGED_CASE(6, V, 1) CGH_STAGED_CASE(7, V, 1) CGH_STAGED_CASE(8, V, 1)                  \
+        default:                                                                                                                 \
+            CGH_STAGED_CASE(0, V, 1)                                                                                             \
         }                                                                                                                        \
     } else {                                                                                                                     \
-        switch (m->K) {                                                                                                          \
+        switch (g_cfg.ell_generic ? 0 : m->K) {                                                                                  \
             CGH_STAGED_CASE(13, V, 3) CGH_STAGED_CASE(26, V, 3)                                                                  \
+        default: /* any other width: run-time K */                                                                               \
+            CGH_STAGED_CASE(0, V, 3)                                                                                             \
         }                                                                                                                        \
     }
     if (var == 1) {

@@ -149,7 +149,7 @@ int     cgh_matrix_dict_offsets(const cgh_matrix *m);
  * 512-row tile lie together, so a workgroup reads one contiguous run per tile instead of K runs n*8 bytes apart (wide rows,
  * K > 8; costs 8 more bytes of HBM per stored slot; CGH_ELL_BLOCKED=0 keeps 2).  0 = int32 columns / not built / other layouts. */
 int     cgh_matrix_dict_mode(const cgh_matrix *m);
-/* Wide banded rows (dict_mode 3): the SpMV stages the windows of x a 512-row tile reads (row + d for the matrix's distinct
+/* Wide banded rows (dict_mode 3, any width above 8 slots): the SpMV stages the windows of x a 512-row tile reads (row + d for the matrix's distinct
  * offsets d, overlapping runs merged) in LDS with coalesced loads and gathers from there instead of from L1 / L2.  Returns
  * the doubles of LDS per workgroup in use for this matrix, 0 if its launches gather from the caches (CGH_ELL_STAGE=0 forces
  * that; the windows of a matrix must fit 44 KiB and all its columns lie below n). */
