@@ -14,6 +14,11 @@
 //
 // DOT=true additionally leaves sum_i x[i]*y[i] of the workgroup's rows in partials[blockIdx.x]
 // (CG: x is p, y is Ap; saves a full re-read of p and Ap).
+//
+// Banded matrices (<= 255 distinct col - row offsets) get derived copies at their first SpMV (ell_dict_try_build): 1-byte
+// column codes; rows wider than 8 slots also the values and code words tile-blocked (slot_at<3>) and, if the windows of x
+// a tile reads fit 44 KiB of LDS, the kernel that gathers from LDS (spmv_ell_staged).  Same operands in the same order
+// everywhere: every variant gives the same bits.
 #include <algorithm>
 #include <mutex>
 #include <vector>
