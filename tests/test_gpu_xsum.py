@@ -70,6 +70,63 @@ def test_strict_cg_through_parallel_sums(cga, monkeypatch, tag):
     assert np.array_equal(bits(x.to_host()), bits(g["cg_x"]))
 
 
+def test_full_size_27point_256cubed_strict_bit_exact(cga):
+    """The wide-row kernels at full size against the reference's own code: 256^3 27-point (K = 26: tile-blocked copies of
+    values and code words, x gathered from windows staged in LDS), one SpMV of a vector with entries of every magnitude
+    and 8 strict CG iterations -- y, (res, rr, alpha, beta) and x bit-identical to oracle/_ref/libref.so (else the port)."""
+    import ctypes as C
+    import os
+    N, iters = 256, 8
+    n = N ** 3
+    b = cga.DeviceVector(n); x = cga.DeviceVector(n)
+    A = cga.Matrix.poisson(N, N, N, 27, 0x5EED0001, cga.LAYOUT_ELL, b)
+    ev, ec = A.download_ell(); diag = A.download_diag(); bh = b.to_host()
+    K = A.K
+    assert K == 26
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    ref_so = os.path.join(root, "oracle", "_ref", "libref.so")
+    if os.path.exists(ref_so):
+        R = C.CDLL(ref_so)
+        R.vec_dot.restype = C.c_double; R.vec_l1norm.restype = C.c_double
+        R.vec_axpy.argtypes = [O.dp, O.dp, C.c_double, O.dp, C.c_int]
+        mv = lambda v, out: R.mv_ell_symmetric_full_colmajor(n, K, O.D(diag), O.D(ev), O.I(ec), O.D(v), O.D(out))
+        dot = lambda u, v: R.vec_dot(O.D(u), O.D(v), n)
+        l1 = lambda u: R.vec_l1norm(O.D(u), n)
+        axpy = lambda a_, b_, al, out: R.vec_axpy(O.D(a_), O.D(b_), al, O.D(out), n)
+    else:
+        L = O.lib()
+        mv = lambda v, out: L.orc_mv_ell_symmetric_full_colmajor(n, K, O.D(diag), O.D(ev), O.I(ec), O.D(v), O.D(out))
+        dot = lambda u, v: L.orc_vec_dot(O.D(u), O.D(v), n)
+        l1 = lambda u: L.orc_vec_l1norm(O.D(u), n)
+        axpy = lambda a_, b_, al, out: L.orc_vec_axpy(O.D(a_), O.D(b_), al, O.D(out), n)
+    # one SpMV
+    rng = np.random.default_rng(27)
+    vh = rng.standard_normal(n) * np.exp2(rng.integers(-30, 30, n))
+    want_y = np.empty(n)
+    mv(vh, want_y)
+    v = cga.DeviceVector.from_host(vh); y = cga.DeviceVector(n)
+    A.spmv(v, y)
+    assert A.dict_mode == 3 and A.stage_doubles > 0          # the kernels this test is about
+    assert np.array_equal(bits(y.to_host()), bits(want_y))
+    del v, y, vh, want_y
+    # strict CG
+    xr = np.zeros(n); r = bh.copy(); p = bh.copy(); Ap = np.empty(n)
+    rr = dot(r, r)
+    want = [[l1(r) / 2.0, rr, np.nan, np.nan]]
+    for it in range(1, iters + 1):
+        mv(p, Ap)
+        alpha = rr / dot(p, Ap)
+        axpy(xr, p, alpha, xr); axpy(r, Ap, -alpha, r)
+        rr_new = dot(r, r)
+        beta = rr_new / rr
+        want.append([l1(r) / 2.0, rr_new, alpha, beta])
+        axpy(r, p, beta, p)
+        rr = rr_new
+    rep, hist = cga.cg_solve(A, b, x, fixed_iters=iters, strict=1)
+    assert same_bits_nan(hist[:iters + 1], np.array(want))
+    assert np.array_equal(bits(x.to_host()), bits(xr))
+
+
 def test_full_size_256cubed_strict_bit_exact(cga, monkeypatch):
     """BASELINE config 3 at full size: strict mode (parallel order-exact sums) against the reference's own arithmetic
     on the host (oracle/_ref/libref.so when present, else the oracle port), 50 iterations: (res, rr, alpha, beta) and x
