@@ -342,7 +342,7 @@ def main():
             "1-byte dictionary-coded columns, %d offsets%s" % (
                 A.dict_offsets, ("; values and code words tile-blocked: the %d slots of every 512-row tile together" % A.K
                                  if A.dict_mode == 3 else "") +
-                ("; x gathered from %d doubles of windows staged in LDS per tile" % A.stage_doubles if A.stage_doubles else ""))
+                ("; x gathered from %d doubles of windows staged in LDS per staging round" % A.stage_doubles if A.stage_doubles else ""))
             if A.dict_offsets > 0 else "int32 columns")
     out = {
         "metric": "CG iters/sec + SpMV achieved HBM GB/s (% of peak): value = CG iterations/s, the SpMV figures are in roofline",

@@ -378,7 +378,7 @@ def run(args, rank, world, local_rank, shape, seed):
                                            "bytes_per_launch": int(extra["alg_spmv"]), "ms_per_launch": extra["spmv_ms"],
                                            "traffic": None},
                               "iter_GBs_algorithmic": (12 * extra["nnz_off"] + 96 * extra["n"]) / (extra["ms_step"] * 1e-3) / 1e9,
-                              "one_gpu_reference": "profiles/r03_bench_p27_512_n1.json (120 it/s on one MI355X)"}
+                              "one_gpu_reference": "profiles/r03_bench_p27_512_n1.json (124 it/s on one MI355X)"}
         print(json.dumps(out), flush=True)
     barrier()
     cga.lib().cgh_comm_destroy()

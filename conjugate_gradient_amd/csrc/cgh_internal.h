@@ -77,6 +77,7 @@ struct cgh_matrix {
     // gathers served from LDS (spmv_ell_staged): windows of x per tile, relative to the tile's first row; 0 windows = not in use.
     // off_tab then holds 768 ints: the offsets, and per code the LDS index of lane 0's operand for its first / second row
     mutable int            stage_nwin = 0, stage_total = 0, stage_first[8] = {0}, stage_len[8] = {0}, stage_base[8] = {0};
+    mutable int            stage_tiles = 1;        // 512-row tiles per staging round (2 for wide rows if the plan fits)
     mutable bool           stage_any_row = false;  // every column lies below n: any row range may be staged (else only interior rows)
     mutable double        *vals_blk = nullptr; // dict_mode 3 (wide rows): the values with the K slots of every 512-row tile together
     bool     owns = true;
@@ -127,6 +128,7 @@ struct cgh_config {
     int    ell_variant = -1;    // CGH_ELL_VARIANT: cache-hint variant of the ELL SpMV, -1 = by working-set size
     int    ell_blocked = 1;     // CGH_ELL_BLOCKED: wide dictionary-coded rows (K > 8) read tile-blocked copies of values and codes (0: slot-major)
     int    ell_stage = 1;       // CGH_ELL_STAGE: 1 = wide dictionary-coded ELL rows (tile-blocked, K = 13 / 26) gather x from windows staged in LDS; 2 = narrow rows too; 0 = everything from L1 / L2
+    int    ell_stage_tiles = 2; // CGH_ELL_STAGE_TILES: 512-row tiles per staging round of wide rows: 2 = two where that saves >= 30 % of the staged doubles per row and fits 50 KiB; 1 = always one; 3 = two whenever they fit
     int    ell_wgs = 0;         // CGH_ELL_WGS: workgroups per CU of the ELL SpMV's tile walk (0 = by kernel: 5 narrow byte-coded rows, else 8)
     double llc_mb = 224.0;      // CGH_LLC_MB: working sets below this many MiB run without streaming hints
     int    csr_window = 1024;   // CGH_CSR_WINDOW: entries per row block of the CSR stream kernel (512 | 1024 | 2048)

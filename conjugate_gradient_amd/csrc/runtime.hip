@@ -55,6 +55,7 @@ static void read_env_knobs()
     g_cfg.ell_dict = env_int("CGH_ELL_DICT", g_cfg.ell_dict);
     g_cfg.ell_blocked = env_int("CGH_ELL_BLOCKED", g_cfg.ell_blocked);
     g_cfg.ell_stage = env_int("CGH_ELL_STAGE", g_cfg.ell_stage);
+    g_cfg.ell_stage_tiles = env_int("CGH_ELL_STAGE_TILES", g_cfg.ell_stage_tiles);
     g_cfg.ell_variant = env_int("CGH_ELL_VARIANT", g_cfg.ell_variant);
     if (getenv("CGH_LLC_MB")) g_cfg.llc_mb = atof(getenv("CGH_LLC_MB"));
     g_cfg.csr_window = env_int("CGH_CSR_WINDOW", g_cfg.csr_window);

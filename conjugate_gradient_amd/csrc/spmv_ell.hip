@@ -243,7 +243,9 @@ struct cgh_stage_plan {
     int first[8], len[8], base[8];
 };
 
-template <int KT, int DOT, int VAR, int DICT>
+// TT: 512-row tiles per staging round.  With two, neighbouring tiles share what they stage -- a 512-row tile of an nx = 512 grid
+// is ONE grid line and stages three lines per plane for it, two tiles stage four for two -- at twice the LDS per workgroup.
+template <int KT, int DOT, int VAR, int DICT, int TT>
 __global__ __launch_bounds__(CGH_BLOCK) void spmv_ell_staged(int64_t n, int Krt, const double *__restrict__ diag, const double *__restrict__ vals,
                                                             const void *__restrict__ cols, const int *__restrict__ stage_tab,
                                                             const double *__restrict__ x, double *__restrict__ y,
@@ -255,103 +257,54 @@ __global__ __launch_bounds__(CGH_BLOCK) void spmv_ell_staged(int64_t n, int Krt,
     __shared__ int    t0s[256], t1s[256];
     if (done != nullptr && *done != 0) return;
     t0s[threadIdx.x] = stage_tab[threadIdx.x];
-    t1s[threadIdx.x] = stage_tab[256 + threadIdx.x];  // (the first tile's barrier comes before anybody reads them)
+    t1s[threadIdx.x] = stage_tab[256 + threadIdx.x];  // (the first round's barrier comes before anybody reads them)
     const int64_t pair0 = row_begin >> 1, pairs = (row_end >> 1) - pair0;
     double        local = 0.0;
-    const int64_t tiles = (pairs + CGH_BLOCK - 1) / CGH_BLOCK;
+    constexpr int RP = CGH_BLOCK * TT;  // row pairs per staging round
+    const int64_t tiles = (pairs + RP - 1) / RP;
     const int64_t tiles64 = (tiles + 63) & ~(int64_t)63;
     constexpr bool NT = (VAR & 2) != 0, NTSTORE = (VAR & 8) != 0;
     const bool     REMAP = (VAR & 1) != 0 && tiles > CGH_ELL_SMALL_TILES;
     constexpr int  NW = (KT + 3) / 4;
-    constexpr int  KA = KT > 0 ? KT : 1;  // (array sizes of the compile-time path)
+    constexpr int  KA = KT > 0 ? KT : 1, NWA = DICT >= 2 && NW > 0 ? NW : 1;  // (array sizes of the compile-time path)
     const int      K = KT > 0 ? KT : Krt;
     for (int64_t jj = blockIdx.x; jj < tiles64; jj += gridDim.x) {
         const int64_t j = rev ? tiles64 - 1 - jj : jj;
         const int64_t q = j >> 3;
         const int64_t t = REMAP ? ((q >> 3) << 6) + ((j & 7) << 3) + (q & 7) : j;
-        if (t * CGH_BLOCK >= pairs) continue;  // (the whole workgroup)
-        const int64_t pr = t * CGH_BLOCK + threadIdx.x;
-        const bool    mine = pr < pairs;
-        const int64_t i0 = (pair0 + (mine ? pr : t * CGH_BLOCK)) << 1;
-        if constexpr (KT == 0) {
-            // any width (run-time K): the windows first, then slot after slot -- codes, value, two gathers from LDS
-            const double2 d = *reinterpret_cast<const double2 *>(diag + i0);
-            const double2 xi = *reinterpret_cast<const double2 *>(x + i0);
-            __syncthreads();  // the previous tile's gathers are over
-            const int64_t ts = (pair0 + t * CGH_BLOCK) << 1;
-            for (int wi = 0; wi < sp.nwin; ++wi) {
-                const int     half = sp.len[wi] >> 1, base = sp.base[wi];
-                const int64_t e0 = ts + sp.first[wi];
-                for (int k = threadIdx.x; k < half; k += CGH_BLOCK) {
-                    const int64_t e = e0 + 2 * (int64_t)k;
-                    double2       xv = make_double2(0.0, 0.0);
-                    if (e >= 0 && e < n) xv = *reinterpret_cast<const double2 *>(x + e);
-                    xs[base + k] = xv.x;
-                    xs[base + half + k] = xv.y;
-                }
-            }
-            __syncthreads();
-            if (!mine) continue;
-            double a0 = add_rn(0.0, mul_rn(d.x, xi.x));
-            double a1 = add_rn(0.0, mul_rn(d.y, xi.y));
-            const int nw = (K + 3) / 4;
-            u2_t      w;
-            w.x = w.y = 0;
-#pragma unroll 4
-            for (int s = 0; s < K; ++s) {
-                int c0, c1;
-                if constexpr (DICT >= 2) {
-                    if ((s & 3) == 0)
-                        w = stream_load<NT>(reinterpret_cast<const u2_t *>(reinterpret_cast<const unsigned *>(cols) + slot_at<DICT>(n, nw, s >> 2, i0)));
-                    c0 = (w.x >> (8 * (s & 3))) & 0xff;
-                    c1 = (w.y >> (8 * (s & 3))) & 0xff;
-                } else {
-                    const unsigned short cc = stream_load<NT>(reinterpret_cast<const unsigned short *>(cols) + (((int64_t)s * n + i0) >> 1));
-                    c0 = cc & 0xff;
-                    c1 = cc >> 8;
-                }
-                const d2_t   v = stream_load<NT>(reinterpret_cast<const d2_t *>(vals + slot_at<DICT>(n, K, s, i0)));
-                const double g0 = xs[t0s[c0] + (int)threadIdx.x];
-                const double g1 = xs[t1s[c1] + (int)threadIdx.x];
-                const double p0 = madd_rn(a0, v.x, g0);
-                const double p1 = madd_rn(a1, v.y, g1);
-                a0 = c0 != 255 ? p0 : a0;
-                a1 = c1 != 255 ? p1 : a1;
-            }
-            if constexpr (NTSTORE) {
-                d2_t o;
-                o.x = a0;
-                o.y = a1;
-                __builtin_nontemporal_store(o, reinterpret_cast<d2_t *>(y + i0));
-            } else {
-                *reinterpret_cast<double2 *>(y + i0) = make_double2(a0, a1);
-            }
-            if constexpr (DOT == 1) local += xi.x * a0 + xi.y * a1;
-            if constexpr (DOT == 2) {
-                const double qsum = wave_sum_lane63(xi.x * a0 + xi.y * a1);
-                if ((threadIdx.x & 63) == 63) partials[pr >> 6] = qsum;
-            }
-            continue;
-        }
-        // the tile's matrix entries first: they have the longest way
-        d2_t v[KA];
-        u2_t w[DICT >= 2 ? (NW > 0 ? NW : 1) : 1];
+        if (t * RP >= pairs) continue;  // (the whole workgroup)
+        // compile-time width: the first tile's matrix entries go out before the staging (they have the longest way)
+        d2_t           v[KA];
+        u2_t           w[NWA];
         unsigned short cb[DICT >= 2 ? 1 : KA];
-        if constexpr (DICT >= 2) {
+        auto load_entries = [&](int64_t i0) {
+            if constexpr (KT > 0) {
+                if constexpr (DICT >= 2) {
 #pragma unroll
-            for (int qq = 0; qq < NW; ++qq)
-                w[qq] = stream_load<NT>(reinterpret_cast<const u2_t *>(reinterpret_cast<const unsigned *>(cols) + slot_at<DICT>(n, NW, qq, i0)));
-        } else {
+                    for (int qq = 0; qq < NW; ++qq)
+                        w[qq] = stream_load<NT>(reinterpret_cast<const u2_t *>(reinterpret_cast<const unsigned *>(cols) + slot_at<DICT>(n, NW, qq, i0)));
+                } else {
 #pragma unroll
-            for (int s = 0; s < KT; ++s)
-                cb[s] = stream_load<NT>(reinterpret_cast<const unsigned short *>(cols) + (((int64_t)s * n + i0) >> 1));
-        }
+                    for (int s = 0; s < KT; ++s)
+                        cb[s] = stream_load<NT>(reinterpret_cast<const unsigned short *>(cols) + (((int64_t)s * n + i0) >> 1));
+                }
 #pragma unroll
-        for (int s = 0; s < KT; ++s) v[s] = stream_load<NT>(reinterpret_cast<const d2_t *>(vals + slot_at<DICT>(n, KT, s, i0)));
-        const double2 d = *reinterpret_cast<const double2 *>(diag + i0);
-        const double2 xi = *reinterpret_cast<const double2 *>(x + i0);
-        __syncthreads();  // the previous tile's gathers are over
-        const int64_t ts = (pair0 + t * CGH_BLOCK) << 1;
+                for (int s = 0; s < KT; ++s) v[s] = stream_load<NT>(reinterpret_cast<const d2_t *>(vals + slot_at<DICT>(n, KT, s, i0)));
+            }
+        };
+        auto first_row = [&](int sub, bool &mine, int64_t &pr) {
+            pr = t * RP + (int64_t)sub * CGH_BLOCK + threadIdx.x;
+            mine = pr < pairs;
+            return (pair0 + (mine ? pr : t * RP + (int64_t)sub * CGH_BLOCK)) << 1;  // (idle lanes: the tile's first rows)
+        };
+        bool    mine;
+        int64_t pr;
+        int64_t i0 = first_row(0, mine, pr);
+        load_entries(i0);
+        double2 d = *reinterpret_cast<const double2 *>(diag + i0);
+        double2 xi = *reinterpret_cast<const double2 *>(x + i0);
+        __syncthreads();  // the previous round's gathers are over
+        const int64_t ts = (pair0 + t * RP) << 1;
         for (int wi = 0; wi < sp.nwin; ++wi) {
             const int     half = sp.len[wi] >> 1, base = sp.base[wi];
             const int64_t e0 = ts + sp.first[wi];  // even
@@ -364,38 +317,77 @@ __global__ __launch_bounds__(CGH_BLOCK) void spmv_ell_staged(int64_t n, int Krt,
             }
         }
         __syncthreads();
-        if (!mine) continue;  // (no barrier is skipped: the next one is the next tile's first)
-        double a0 = add_rn(0.0, mul_rn(d.x, xi.x));
-        double a1 = add_rn(0.0, mul_rn(d.y, xi.y));
 #pragma unroll
-        for (int s = 0; s < KT; ++s) {
-            int c0, c1;
-            if constexpr (DICT >= 2) {
-                c0 = (w[s >> 2].x >> (8 * (s & 3))) & 0xff;
-                c1 = (w[s >> 2].y >> (8 * (s & 3))) & 0xff;
-            } else {
-                c0 = cb[s] & 0xff;
-                c1 = cb[s] >> 8;
+        for (int sub = 0; sub < TT; ++sub) {
+            if (sub > 0) {
+                if (t * RP + (int64_t)sub * CGH_BLOCK >= pairs) break;  // (the whole workgroup; no barrier inside this loop)
+                i0 = first_row(sub, mine, pr);
+                load_entries(i0);
+                d = *reinterpret_cast<const double2 *>(diag + i0);
+                xi = *reinterpret_cast<const double2 *>(x + i0);
             }
-            const double g0 = xs[t0s[c0] + (int)threadIdx.x];
-            const double g1 = xs[t1s[c1] + (int)threadIdx.x];
-            const double p0 = madd_rn(a0, v[s].x, g0);
-            const double p1 = madd_rn(a1, v[s].y, g1);
-            a0 = c0 != 255 ? p0 : a0;
-            a1 = c1 != 255 ? p1 : a1;
-        }
-        if constexpr (NTSTORE) {
-            d2_t o;
-            o.x = a0;
-            o.y = a1;
-            __builtin_nontemporal_store(o, reinterpret_cast<d2_t *>(y + i0));
-        } else {
-            *reinterpret_cast<double2 *>(y + i0) = make_double2(a0, a1);
-        }
-        if constexpr (DOT == 1) local += xi.x * a0 + xi.y * a1;
-        if constexpr (DOT == 2) {
-            const double qsum = wave_sum_lane63(xi.x * a0 + xi.y * a1);  // (n % 128 == 0: every wave is full or idle)
-            if ((threadIdx.x & 63) == 63) partials[pr >> 6] = qsum;
+            if (!mine) continue;
+            const int     lane = (int)threadIdx.x + sub * CGH_BLOCK;  // row pair inside the staged round
+            double        a0 = add_rn(0.0, mul_rn(d.x, xi.x));
+            double        a1 = add_rn(0.0, mul_rn(d.y, xi.y));
+            if constexpr (KT > 0) {
+#pragma unroll
+                for (int s = 0; s < KT; ++s) {
+                    int c0, c1;
+                    if constexpr (DICT >= 2) {
+                        c0 = (w[s >> 2].x >> (8 * (s & 3))) & 0xff;
+                        c1 = (w[s >> 2].y >> (8 * (s & 3))) & 0xff;
+                    } else {
+                        c0 = cb[s] & 0xff;
+                        c1 = cb[s] >> 8;
+                    }
+                    const double g0 = xs[t0s[c0] + lane];
+                    const double g1 = xs[t1s[c1] + lane];
+                    const double p0 = madd_rn(a0, v[s].x, g0);
+                    const double p1 = madd_rn(a1, v[s].y, g1);
+                    a0 = c0 != 255 ? p0 : a0;
+                    a1 = c1 != 255 ? p1 : a1;
+                }
+            } else {
+                // any width (run-time K): slot after slot -- codes, value, two gathers from LDS
+                const int nw = (K + 3) / 4;
+                u2_t      wr;
+                wr.x = wr.y = 0;
+#pragma unroll 4
+                for (int s = 0; s < K; ++s) {
+                    int c0, c1;
+                    if constexpr (DICT >= 2) {
+                        if ((s & 3) == 0)
+                            wr = stream_load<NT>(reinterpret_cast<const u2_t *>(reinterpret_cast<const unsigned *>(cols) + slot_at<DICT>(n, nw, s >> 2, i0)));
+                        c0 = (wr.x >> (8 * (s & 3))) & 0xff;
+                        c1 = (wr.y >> (8 * (s & 3))) & 0xff;
+                    } else {
+                        const unsigned short cc = stream_load<NT>(reinterpret_cast<const unsigned short *>(cols) + (((int64_t)s * n + i0) >> 1));
+                        c0 = cc & 0xff;
+                        c1 = cc >> 8;
+                    }
+                    const d2_t   vv = stream_load<NT>(reinterpret_cast<const d2_t *>(vals + slot_at<DICT>(n, K, s, i0)));
+                    const double g0 = xs[t0s[c0] + lane];
+                    const double g1 = xs[t1s[c1] + lane];
+                    const double p0 = madd_rn(a0, vv.x, g0);
+                    const double p1 = madd_rn(a1, vv.y, g1);
+                    a0 = c0 != 255 ? p0 : a0;
+                    a1 = c1 != 255 ? p1 : a1;
+                }
+            }
+            if constexpr (NTSTORE) {
+                d2_t o;
+                o.x = a0;
+                o.y = a1;
+                __builtin_nontemporal_store(o, reinterpret_cast<d2_t *>(y + i0));
+            } else {
+                *reinterpret_cast<double2 *>(y + i0) = make_double2(a0, a1);
+            }
+            if constexpr (DOT == 1) local += xi.x * a0 + xi.y * a1;
+            if constexpr (DOT == 2) {
+                const double qsum = wave_sum_lane63(xi.x * a0 + xi.y * a1);  // (n % 128 == 0: every wave is full or idle)
+                if ((threadIdx.x & 63) == 63) partials[pr >> 6] = qsum;
+            }
         }
     }
     if constexpr (DOT == 1) {
@@ -607,13 +599,14 @@ __global__ __launch_bounds__(256) void ell_max_col(int64_t total, const int *__r
     if ((threadIdx.x & 63) == 0) atomicMax(out, m);
 }
 
-constexpr int STAGE_MAX_WINDOWS = 8, STAGE_MAX_DOUBLES = 5632;  // 44 KiB of LDS per workgroup at most
+// LDS per workgroup at most: 44 KiB with one tile per staging round, 50 KiB with two (three workgroups of 153 VGPRs per CU still fit)
+constexpr int STAGE_MAX_WINDOWS = 8, STAGE_MAX_DOUBLES = 5632, STAGE_MAX_DOUBLES_2 = 6400;
 
 // Windows of x a 512-row tile needs, from the sorted offsets: [d, d + 512) per offset d, overlapping or abutting runs
 // merged; starts and lengths even (16-byte loads), each window stored as even entries then odd entries.  tab[256 + c] /
 // tab[512 + c]: LDS index of the operand of lane 0's first / second row for code c.  Returns false if the plan does not
 // fit (too many windows, too much LDS).
-bool ell_stage_plan(const std::vector<int> &offs, int count, const cgh_matrix *m, std::vector<int> &tab)
+bool ell_stage_plan(const std::vector<int> &offs, int count, const cgh_matrix *m, std::vector<int> &tab, int rows, int max_doubles)
 {
     int nwin = 0, total = 0, first[8], len[8], base[8], win_of[256];
     for (int k = 0; k < count;) {
@@ -622,22 +615,22 @@ bool ell_stage_plan(const std::vector<int> &offs, int count, const cgh_matrix *m
         int       last = offs[k];
         win_of[k] = nwin;
         int kk = k + 1;
-        while (kk < count && (int64_t)offs[kk] < (int64_t)last + 512) {
+        while (kk < count && (int64_t)offs[kk] < (int64_t)last + rows) {
             last = offs[kk];
             win_of[kk] = nwin;
             ++kk;
         }
-        const int64_t l = ((int64_t)last - f + 512 + 1) & ~(int64_t)1;
-        if (l > STAGE_MAX_DOUBLES) return false;
+        const int64_t l = ((int64_t)last - f + rows + 1) & ~(int64_t)1;
+        if (l > max_doubles) return false;
         first[nwin] = f;
         len[nwin] = (int)l;
         base[nwin] = total;
         total += (int)l;
-        if (total > STAGE_MAX_DOUBLES) return false;
+        if (total > max_doubles) return false;
         ++nwin;
         k = kk;
     }
-    if (nwin == 0 || total < 512) return false;
+    if (nwin == 0 || total < rows) return false;
     for (int c = 0; c < 256; ++c) tab[256 + c] = tab[512 + c] = 0;
     for (int c = 0; c < count; ++c) {
         const int w = win_of[c], e = offs[c] - first[w], half = len[w] >> 1;
@@ -646,6 +639,7 @@ bool ell_stage_plan(const std::vector<int> &offs, int count, const cgh_matrix *m
     }
     m->stage_nwin = nwin;
     m->stage_total = total;
+    m->stage_tiles = rows / 512;
     for (int w = 0; w < nwin; ++w) {
         m->stage_first[w] = first[w];
         m->stage_len[w] = len[w];
@@ -698,7 +692,16 @@ void ell_dict_try_build(const cgh_matrix *m, hipStream_t s)
             if (hipGetLastError() == hipSuccess && cgh_d2h(&hmx, mx, sizeof(int)) == CGH_OK) {
                 // columns at or beyond n (the halo entries of a multi-GPU block) are never staged (the windows end at n): such a
                 // matrix is served for launches over its interior rows only (cgh_spmv_opts::interior_rows)
-                staged = ell_stage_plan(offs, count, m, tab);
+                // Wide rows: two tiles per staging round where that saves at least 30 % of the staged doubles per row -- an
+                // nx = 512 grid, whose 512-row tile is ONE grid line staging three lines per plane (27-point 512^3: 6.22 ->
+                // 5.59 ms; 512x512x128: 1.620 -> 1.590); at nx = 256 it saves 25 % and loses (0.718 -> 0.731 ms: the second
+                // tile's matrix loads do not overlap any staging).  CGH_ELL_STAGE_TILES=1: always one; 3: two whenever they fit.
+                const bool wide_rows = m->K > 8;
+                const bool ok2 = wide_rows && g_cfg.ell_stage_tiles >= 2 && ell_stage_plan(offs, count, m, tab, 1024, STAGE_MAX_DOUBLES_2);
+                const int  total2 = m->stage_total;
+                staged = ell_stage_plan(offs, count, m, tab, 512, STAGE_MAX_DOUBLES);
+                if (ok2 && (!staged || g_cfg.ell_stage_tiles >= 3 || (int64_t)total2 * 10 <= (int64_t)m->stage_total * 14))
+                    staged = ell_stage_plan(offs, count, m, tab, 1024, STAGE_MAX_DOUBLES_2);
                 m->stage_any_row = (int64_t)hmx < m->n;
             }
         }
@@ -872,10 +875,20 @@ static bool launch_staged(const cgh_matrix *m, int var, int grid, hipStream_t s,
     }
     const size_t  shm = sizeof(double) * (size_t)sp.total;
     const double *vals = wide ? m->vals_blk : m->vals;
+#define CGH_STAGED_LAUNCH(KK, V, MODE, TILES)                                                                                    \
+    hipLaunchKernelGGL((spmv_ell_staged<KK, DOT, V, MODE, TILES>), dim3(grid), dim3(CGH_BLOCK), shm, s, m->n, m->K, (const double *)m->diag, \
+                       vals, (const void *)m->cols8, (const int *)m->off_tab + 256, x, y, partials, done, rev, rb, re, sp);
 #define CGH_STAGED_CASE(KK, V, MODE)                                                                                             \
     case KK:                                                                                                                     \
-        hipLaunchKernelGGL((spmv_ell_staged<KK, DOT, V, MODE>), dim3(grid), dim3(CGH_BLOCK), shm, s, m->n, m->K, (const double *)m->diag, vals, \
-                           (const void *)m->cols8, (const int *)m->off_tab + 256, x, y, partials, done, rev, rb, re, sp);        \
+        CGH_STAGED_LAUNCH(KK, V, MODE, 1)                                                                                        \
+        break;
+#define CGH_STAGED_CASE_W(KK, V)                                                                                                 \
+    case KK:                                                                                                                     \
+        if (m->stage_tiles == 2) {                                                                                               \
+            CGH_STAGED_LAUNCH(KK, V, 3, 2)                                                                                       \
+        } else {                                                                                                                 \
+            CGH_STAGED_LAUNCH(KK, V, 3, 1)                                                                                       \
+        }                                                                                                                        \
         break;
 #define CGH_STAGED_VAR(V)                                                                                                        \
     if (narrow) {                                                                                                                \
@@ -887,9 +900,9 @@ static bool launch_staged(const cgh_matrix *m, int var, int grid, hipStream_t s,
         }                                                                                                                        \
     } else {                                                                                                                     \
         switch (g_cfg.ell_generic ? 0 : m->K) {                                                                                  \
-            CGH_STAGED_CASE(13, V, 3) CGH_STAGED_CASE(26, V, 3)                                                                  \
+            CGH_STAGED_CASE_W(13, V) CGH_STAGED_CASE_W(26, V)                                                                    \
         default: /* any other width: run-time K */                                                                               \
-            CGH_STAGED_CASE(0, V, 3)                                                                                             \
+            CGH_STAGED_CASE_W(0, V)                                                                                              \
         }                                                                                                                        \
     }
     if (var == 1) {
@@ -901,6 +914,8 @@ static bool launch_staged(const cgh_matrix *m, int var, int grid, hipStream_t s,
     }
 #undef CGH_STAGED_VAR
 #undef CGH_STAGED_CASE
+#undef CGH_STAGED_CASE_W
+#undef CGH_STAGED_LAUNCH
     return true;
 }
 

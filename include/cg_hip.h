@@ -152,7 +152,8 @@ int     cgh_matrix_dict_mode(const cgh_matrix *m);
 /* Wide banded rows (dict_mode 3, any width above 8 slots): the SpMV stages the windows of x a 512-row tile reads (row + d for the matrix's distinct
  * offsets d, overlapping runs merged) in LDS with coalesced loads and gathers from there instead of from L1 / L2.  Returns
  * the doubles of LDS per workgroup in use for this matrix, 0 if its launches gather from the caches (CGH_ELL_STAGE=0 forces
- * that; the windows of a matrix must fit 44 KiB and all its columns lie below n). */
+ * that; the windows of a matrix must fit 44 KiB -- 50 KiB where two 512-row tiles are staged together, CGH_ELL_STAGE_TILES --
+ * and all its columns lie below n). */
 int     cgh_matrix_stage_doubles(const cgh_matrix *m);
 /* Download as slot-major full ELL of width K=cgh_matrix_width (any layout); buffers hold n*K entries. */
 int     cgh_matrix_download_ell(const cgh_matrix *m, double *ell_vals, int *ell_cols);

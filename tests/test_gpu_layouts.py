@@ -181,22 +181,28 @@ def test_tile_blocked_wide_rows_same_bits(cga, monkeypatch, shape, generic):
     b = cga.DeviceVector.from_host(s["source"]); sol = cga.DeviceVector(n)
     setknob(monkeypatch, "CGH_ELL_GENERIC", generic)
     got = {}
-    for blocked, stage in (("0", "1"), ("1", "0"), ("1", "1")):
+    for blocked, stage, tiles in (("0", "1", "2"), ("1", "0", "2"), ("1", "1", "1"), ("1", "1", "3")):
         setknob(monkeypatch, "CGH_ELL_BLOCKED", blocked)
         setknob(monkeypatch, "CGH_ELL_STAGE", stage)
+        setknob(monkeypatch, "CGH_ELL_STAGE_TILES", tiles)      # 3: two 512-row tiles per staging round whenever they fit
         A = cga.Matrix.from_coo(n, s["diag"], s["upper"], s["rows"], s["cols"], cga.LAYOUT_ELL)
         A.spmv(x, y)
         rep, hist = cga.cg_solve(A, b, sol, max_iter=40, tol=1e-9, strict=1)
+        xs_ = sol.to_host()
         rep0, hist0 = cga.cg_solve(A, b, sol, max_iter=40, tol=1e-9, strict=0)
-        got[blocked + stage] = (A.dict_mode, y.to_host(), hist, sol.to_host(), hist0, A.stage_doubles)
-    assert got["01"][0] == 2 and got["10"][0] == 3 and got["11"][0] == 3
+        got[blocked + stage + (tiles if blocked + stage == "11" else "")] = (A.dict_mode, y.to_host(), hist, xs_, hist0, A.stage_doubles)
+    assert got["01"][0] == 2 and got["10"][0] == 3 and got["111"][0] == 3 and got["113"][0] == 3
     # gathers from LDS: the tile-blocked layout only (compile-time width 26, or the run-time-width kernel)
-    assert got["01"][5] == 0 and got["10"][5] == 0 and got["11"][5] > 0
+    assert got["01"][5] == 0 and got["10"][5] == 0 and got["111"][5] > 0 and got["113"][5] > got["111"][5]
     want = O.mv_coo(n, s["diag"], s["upper"], s["rows"], s["cols"], xh)
     for k in got:
         assert same_bits_nan(got[k][1], want), k
-        assert same_bits_nan(got["01"][2], got[k][2]) and same_bits_nan(got["01"][4], got[k][4]), k
-        assert np.array_equal(bits(got["01"][3]), bits(got[k][3])), k
+        assert same_bits_nan(got["01"][2], got[k][2]), k      # strict: the whole trajectory, whatever kernel and launch shape
+        # throughput mode: per-workgroup partials follow the launch shape (tiles per staging round): within rounding
+        h0, hk = got["01"][4], got[k][4]
+        m_ = min(len(h0), len(hk), 12)
+        assert np.allclose(h0[:m_, :2], hk[:m_, :2], rtol=1e-11, atol=0), k
+        assert np.array_equal(bits(got["01"][3]), bits(got[k][3])), k      # x of the strict solve
 
 
 @pytest.mark.parametrize("K,n,spread", [(13, 3000, 40), (26, 2050, 900), (13, 1538, 8), (26, 5120, 5000), (9, 1100, 30), (18, 4096, 300),
