@@ -600,24 +600,59 @@ __global__ __launch_bounds__(256) void ell_max_col(int64_t total, const int *__r
 }
 
 // LDS per workgroup at most: 44 KiB with one tile per staging round, 50 KiB with two (three workgroups of 153 VGPRs per CU still fit)
+// smallest column stored under each of the `count` sorted offsets (INT_MAX: none).  An offset whose every column lies at or
+// beyond n belongs to halo entries of a multi-GPU block only: interior rows never use it, the staging plan leaves it out.
+__global__ __launch_bounds__(256) void ell_offset_min_col(int64_t total, int64_t n, const int *__restrict__ cols, const int *__restrict__ sorted,
+                                                         int count, int *__restrict__ mincol)
+{
+    __shared__ int tab[256], lmin[256];
+    tab[threadIdx.x] = (int)threadIdx.x < count ? sorted[threadIdx.x] : INT32_MAX;
+    lmin[threadIdx.x] = INT32_MAX;
+    __syncthreads();
+    for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < total; k += (int64_t)gridDim.x * 256) {
+        const int c = cols[k];
+        if (c == -1) continue;
+        const int off = c - (int)(k % n);
+        int       lo = 0, hi = count - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (tab[mid] < off) lo = mid + 1;
+            else hi = mid;
+        }
+        if (c < lmin[lo]) atomicMin(&lmin[lo], c);
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < count && lmin[threadIdx.x] != INT32_MAX) atomicMin(&mincol[threadIdx.x], lmin[threadIdx.x]);
+}
+
 constexpr int STAGE_MAX_WINDOWS = 8, STAGE_MAX_DOUBLES = 5632, STAGE_MAX_DOUBLES_2 = 6400;
 
 // Windows of x a 512-row tile needs, from the sorted offsets: [d, d + 512) per offset d, overlapping or abutting runs
 // merged; starts and lengths even (16-byte loads), each window stored as even entries then odd entries.  tab[256 + c] /
 // tab[512 + c]: LDS index of the operand of lane 0's first / second row for code c.  Returns false if the plan does not
 // fit (too many windows, too much LDS).
-bool ell_stage_plan(const std::vector<int> &offs, int count, const cgh_matrix *m, std::vector<int> &tab, int rows, int max_doubles)
+bool ell_stage_plan(const std::vector<int> &offs, int count, const cgh_matrix *m, std::vector<int> &tab, int rows, int max_doubles,
+                    const std::vector<char> &halo_only)
 {
     int nwin = 0, total = 0, first[8], len[8], base[8], win_of[256];
     for (int k = 0; k < count;) {
+        if (halo_only[k]) {  // (never read by the rows a staged launch serves)
+            win_of[k] = -1;
+            ++k;
+            continue;
+        }
         if (nwin == STAGE_MAX_WINDOWS) return false;
         const int f = offs[k] & ~1;  // rounded down to even
         int       last = offs[k];
         win_of[k] = nwin;
         int kk = k + 1;
-        while (kk < count && (int64_t)offs[kk] < (int64_t)last + rows) {
-            last = offs[kk];
-            win_of[kk] = nwin;
+        while (kk < count && (halo_only[kk] || (int64_t)offs[kk] < (int64_t)last + rows)) {
+            if (halo_only[kk]) {
+                win_of[kk] = -1;
+            } else {
+                last = offs[kk];
+                win_of[kk] = nwin;
+            }
             ++kk;
         }
         const int64_t l = ((int64_t)last - f + rows + 1) & ~(int64_t)1;
@@ -633,6 +668,7 @@ bool ell_stage_plan(const std::vector<int> &offs, int count, const cgh_matrix *m
     if (nwin == 0 || total < rows) return false;
     for (int c = 0; c < 256; ++c) tab[256 + c] = tab[512 + c] = 0;
     for (int c = 0; c < count; ++c) {
+        if (win_of[c] < 0) continue;
         const int w = win_of[c], e = offs[c] - first[w], half = len[w] >> 1;
         tab[256 + c] = base[w] + (e & 1) * half + (e >> 1);
         tab[512 + c] = base[w] + ((e + 1) & 1) * half + ((e + 1) >> 1);
@@ -689,7 +725,23 @@ void ell_dict_try_build(const cgh_matrix *m, hipStream_t s)
         int  hmx = -1;
         if (mx && cgh_h2d(mx, &hmx, sizeof(int)) == CGH_OK) {
             hipLaunchKernelGGL(ell_max_col, dim3(grid), dim3(256), 0, s, total, (const int *)m->cols, mx);
-            if (hipGetLastError() == hipSuccess && cgh_d2h(&hmx, mx, sizeof(int)) == CGH_OK) {
+            std::vector<char> halo_only(256, 0);
+            bool              have = hipGetLastError() == hipSuccess && cgh_d2h(&hmx, mx, sizeof(int)) == CGH_OK;
+            if (have && (int64_t)hmx >= m->n) {
+                // a multi-GPU block: which offsets are used by halo entries only?
+                int *srt = (int *)cgh_alloc(sizeof(int) * 512);
+                std::vector<int> init(512, INT32_MAX);
+                for (int k = 0; k < count; ++k) init[k] = offs[k];
+                have = srt && cgh_h2d(srt, init.data(), sizeof(int) * 512) == CGH_OK;
+                if (have) {
+                    hipLaunchKernelGGL(ell_offset_min_col, dim3(grid), dim3(256), 0, s, total, m->n, (const int *)m->cols, (const int *)srt, count,
+                                       srt + 256);
+                    have = hipGetLastError() == hipSuccess && cgh_d2h(init.data(), srt, sizeof(int) * 512) == CGH_OK;
+                }
+                cgh_free(srt);
+                for (int k = 0; have && k < count; ++k) halo_only[k] = (int64_t)init[256 + k] >= m->n;
+            }
+            if (have) {
                 // columns at or beyond n (the halo entries of a multi-GPU block) are never staged (the windows end at n): such a
                 // matrix is served for launches over its interior rows only (cgh_spmv_opts::interior_rows)
                 // Wide rows: two tiles per staging round where that saves at least 30 % of the staged doubles per row -- an
@@ -697,11 +749,11 @@ void ell_dict_try_build(const cgh_matrix *m, hipStream_t s)
                 // 5.59 ms; 512x512x128: 1.620 -> 1.590); at nx = 256 it saves 25 % and loses (0.718 -> 0.731 ms: the second
                 // tile's matrix loads do not overlap any staging).  CGH_ELL_STAGE_TILES=1: always one; 3: two whenever they fit.
                 const bool wide_rows = m->K > 8;
-                const bool ok2 = wide_rows && g_cfg.ell_stage_tiles >= 2 && ell_stage_plan(offs, count, m, tab, 1024, STAGE_MAX_DOUBLES_2);
+                const bool ok2 = wide_rows && g_cfg.ell_stage_tiles >= 2 && ell_stage_plan(offs, count, m, tab, 1024, STAGE_MAX_DOUBLES_2, halo_only);
                 const int  total2 = m->stage_total;
-                staged = ell_stage_plan(offs, count, m, tab, 512, STAGE_MAX_DOUBLES);
+                staged = ell_stage_plan(offs, count, m, tab, 512, STAGE_MAX_DOUBLES, halo_only);
                 if (ok2 && (!staged || g_cfg.ell_stage_tiles >= 3 || (int64_t)total2 * 10 <= (int64_t)m->stage_total * 14))
-                    staged = ell_stage_plan(offs, count, m, tab, 1024, STAGE_MAX_DOUBLES_2);
+                    staged = ell_stage_plan(offs, count, m, tab, 1024, STAGE_MAX_DOUBLES_2, halo_only);
                 m->stage_any_row = (int64_t)hmx < m->n;
             }
         }
