@@ -49,6 +49,7 @@ void cgh_set_error(const char *fmt, ...);
     } while (0)
 
 // ---------------------------------------------------------------- matrices
+constexpr int CGH_STAGE_WINDOWS = 12;  // windows of x per staging round at most (spmv_ell_staged): e.g. the nine (y, z) lines of a 27-point stencil on a wide grid
 struct cgh_matrix {
     int64_t n = 0;
     int     K = 0;               // max off-diagonals per row
@@ -76,7 +77,8 @@ struct cgh_matrix {
     mutable int            dict_mode = 0;      // 1: cols8 = one byte per entry (slot-major); 2: 4 slots of a row per 32-bit word; 3: the same words and the values tile-blocked (vals_blk)
     // gathers served from LDS (spmv_ell_staged): windows of x per tile, relative to the tile's first row; 0 windows = not in use.
     // off_tab then holds 768 ints: the offsets, and per code the LDS index of lane 0's operand for its first / second row
-    mutable int            stage_nwin = 0, stage_total = 0, stage_first[8] = {0}, stage_len[8] = {0}, stage_base[8] = {0};
+    mutable int            stage_nwin = 0, stage_total = 0, stage_first[CGH_STAGE_WINDOWS] = {0}, stage_len[CGH_STAGE_WINDOWS] = {0},
+                           stage_base[CGH_STAGE_WINDOWS] = {0};
     mutable int            stage_tiles = 1;        // 512-row tiles per staging round (2 for wide rows if the plan fits)
     mutable bool           stage_any_row = false;  // every column lies below n: any row range may be staged (else only interior rows)
     mutable double        *vals_blk = nullptr; // dict_mode 3 (wide rows): the values with the K slots of every 512-row tile together

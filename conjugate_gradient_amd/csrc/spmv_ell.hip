@@ -231,7 +231,7 @@ __global__ __launch_bounds__(CGH_BLOCK) void spmv_ell_r2(int64_t n, int Krt, con
 
 // The same SpMV with the gathers served from LDS (banded matrices with dictionary-coded columns, one full row range).  A
 // tile's 512 rows read x at row + d for the matrix's few distinct offsets d: per offset one contiguous run of 512 entries,
-// and runs of neighbouring offsets overlap -- the plan (host, ell_stage_plan) merges them into at most 8 windows
+// and runs of neighbouring offsets overlap -- the plan (host, ell_stage_plan) merges them into at most 12 windows
 // [first, first + len) relative to the tile's first row (7-point 256^3: 512 + 1024 + 512 doubles, 16 KiB; 27-point: three
 // windows of 1028, 24 KiB).  The workgroup loads the windows with coalesced 16-byte loads -- every line once per tile,
 // where the 2 K gather instructions of a wave requested each line of x again and again from L1 / L2 -- and the lanes
@@ -240,7 +240,7 @@ __global__ __launch_bounds__(CGH_BLOCK) void spmv_ell_r2(int64_t n, int Krt, con
 // operand of lane 0's first / second row; lane j adds j.  Same operands, same order of operations: same bits.
 struct cgh_stage_plan {
     int nwin = 0, total = 0;  // windows; doubles of LDS in all
-    int first[8], len[8], base[8];
+    int first[CGH_STAGE_WINDOWS], len[CGH_STAGE_WINDOWS], base[CGH_STAGE_WINDOWS];
 };
 
 // TT: 512-row tiles per staging round.  With two, neighbouring tiles share what they stage -- a 512-row tile of an nx = 512 grid
@@ -625,7 +625,7 @@ __global__ __launch_bounds__(256) void ell_offset_min_col(int64_t total, int64_t
     if ((int)threadIdx.x < count && lmin[threadIdx.x] != INT32_MAX) atomicMin(&mincol[threadIdx.x], lmin[threadIdx.x]);
 }
 
-constexpr int STAGE_MAX_WINDOWS = 8, STAGE_MAX_DOUBLES = 5632, STAGE_MAX_DOUBLES_2 = 6400;
+constexpr int STAGE_MAX_WINDOWS = CGH_STAGE_WINDOWS, STAGE_MAX_DOUBLES = 5632, STAGE_MAX_DOUBLES_2 = 6400;
 
 // Windows of x a 512-row tile needs, from the sorted offsets: [d, d + 512) per offset d, overlapping or abutting runs
 // merged; starts and lengths even (16-byte loads), each window stored as even entries then odd entries.  tab[256 + c] /
@@ -634,7 +634,7 @@ constexpr int STAGE_MAX_WINDOWS = 8, STAGE_MAX_DOUBLES = 5632, STAGE_MAX_DOUBLES
 bool ell_stage_plan(const std::vector<int> &offs, int count, const cgh_matrix *m, std::vector<int> &tab, int rows, int max_doubles,
                     const std::vector<char> &halo_only)
 {
-    int nwin = 0, total = 0, first[8], len[8], base[8], win_of[256];
+    int nwin = 0, total = 0, first[CGH_STAGE_WINDOWS], len[CGH_STAGE_WINDOWS], base[CGH_STAGE_WINDOWS], win_of[256];
     for (int k = 0; k < count;) {
         if (halo_only[k]) {  // (never read by the rows a staged launch serves)
             win_of[k] = -1;
@@ -920,7 +920,7 @@ static bool launch_staged(const cgh_matrix *m, int var, int grid, hipStream_t s,
     cgh_stage_plan sp;
     sp.nwin = m->stage_nwin;
     sp.total = m->stage_total;
-    for (int w = 0; w < 8; ++w) {
+    for (int w = 0; w < CGH_STAGE_WINDOWS; ++w) {
         sp.first[w] = m->stage_first[w];
         sp.len[w] = m->stage_len[w];
         sp.base[w] = m->stage_base[w];
