@@ -717,7 +717,7 @@ void ell_dict_try_build(const cgh_matrix *m, hipStream_t s)
     std::sort(offs.begin(), offs.end());
     const int count = (int)offs.size();
     offs.resize(256, 0);
-    // gathers from LDS (spmv_ell_staged): only if every column lies below n, and the windows fit
+    // gathers from LDS (spmv_ell_staged): the plan of the windows of x a staging round reads, if they fit
     std::vector<int> tab(768, 0);
     bool             staged = false;
     if (g_cfg.ell_stage && m->n % 2 == 0) {
