@@ -35,7 +35,7 @@ if workload.startswith("pl_"):
     # one SpMV = pb_expand + pb_accumulate; of the latter the instantiation of the timed loop (with p.Ap: the most launches)
     ks = [k for k in F if k.startswith("pb_expand")] + [max((k for k in F if k.startswith("pb_accumulate")), key=lambda k: F[k][1])]
 else:
-    cand = [k for k in F if re.match(r"spmv_ell_r2<\d+, 1, \d+, \d+, 0>", k) or re.match(r"spmv_ell_staged<\d+, 1, \d+, \d+>", k)]
+    cand = [k for k in F if re.match(r"spmv_ell_r2<\d+, 1, \d+, \d+, 0>", k) or re.match(r"spmv_ell_staged<\d+, 1, \d+, \d+, \d+>", k)]
     ks = [max(cand, key=lambda k: F[k][1])]
 by = {}
 total = 0.0
