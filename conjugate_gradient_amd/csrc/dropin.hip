@@ -306,7 +306,11 @@ int spmv_host(const cgh_matrix *m, const double *x, double *y)
 {
     dbuf<double> dx(x, (size_t)m->n), dy((size_t)m->n);
     if (!dx.ok() || !dy.ok()) return -1;
-    if (cgh_spmv(m, dx.p, dy.p) != CGH_OK) return -1;
+    // ONE product with a matrix that is dropped right after it: no derived copies (column dictionary, tile-blocked values,
+    // staging plan -- several passes over the matrix and, for wide rows, its values a second time in HBM) are built for it
+    cgh_spmv_opts so;
+    so.no_alloc = true;
+    if (cgh_launch_spmv(m, dx.p, dy.p, nullptr, nullptr, nullptr, g_cgh.stream, &so) != CGH_OK) return -1;
     return dy.get(y);
 }
 
